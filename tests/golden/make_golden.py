@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/<robot>.npz by running the REFERENCE itself (build container only).
+
+The reference (/root/reference) is imported here, driven by this build's own robot objects
+(gridcodegenerator_amd.robots -- URDFParser is not available offline), and its numpy oracle
+(`_test.py`) plus its integer topology/sparsity bookkeeping are recorded as data.  Only numbers are
+stored: inputs, expected outputs, integer tables and the size constants the reference would emit.
+Nothing from the reference's source text is written anywhere.
+
+Run (build container only; /root/reference does not exist on the GPU box):
+    python tests/golden/make_golden.py
+"""
+import contextlib
+import io
+import os
+import re
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, "/root")
+
+from reference import GRiDCodeGenerator as RefGen  # noqa: E402
+from gridcodegenerator_amd.robots import get_robot  # noqa: E402
+
+NUM_CONFIGS = 8
+SEEDS = {"iiwa7": 101, "atlas30": 102, "mixed5": 103}
+
+
+def make_inputs(n, seed, K=NUM_CONFIGS):
+    """q ~ U(-pi, pi), qd ~ U(-1, 1), u ~ U(-1, 1); fp32-representable values."""
+    rng = np.random.default_rng(seed)
+    q = rng.uniform(-np.pi, np.pi, (K, n)).astype(np.float32).astype(np.float64)
+    qd = rng.uniform(-1.0, 1.0, (K, n)).astype(np.float32).astype(np.float64)
+    u = rng.uniform(-1.0, 1.0, (K, n)).astype(np.float32).astype(np.float64)
+    return q, qd, u
+
+
+def parse_emitted_array(code, name):
+    vals = {}
+    for m in re.finditer(re.escape(name) + r"\[(\d+)\] = static_cast<T>\(([^;]*)\);", code):
+        vals[int(m.group(1))] = float(eval(m.group(2), {"__builtins__": {}}, {}))
+    return np.array([vals[i] for i in range(len(vals))], dtype=np.float64)
+
+
+def main():
+    for name, seed in SEEDS.items():
+        robot = get_robot(name)
+        n = robot.get_num_pos()
+        g = RefGen(robot)
+        q, qd, u = make_inputs(n, seed)
+        out = dict(q=q, qd=qd, u=u, seed=np.int64(seed))
+        c0 = []; c1 = []; vs = []; as_ = []; fs = []; Mup = []; Mdense = []; qdds = []
+        dc0 = []; dc1 = []; dfs = []; Us = []; Dinvs = []
+        sink = io.StringIO()
+        with contextlib.redirect_stdout(sink):  # the reference prints unconditionally (_test.py:250-253)
+            for k in range(NUM_CONFIGS):
+                (c, v, a, f) = g.test_rnea(q[k], qd[k], None)           # default GRAVITY=-9.81 == kernel +9.81
+                c0.append(c)
+                Mi_up = g.test_minv(q[k], False)
+                Mi = g.test_minv(q[k], True)
+                (_, _, U, Dinv) = g.test_minv_bpass(q[k])
+                qdd = Mi @ (u[k] - c)
+                (cq, v, a, f) = g.test_rnea(q[k], qd[k], qdd)
+                c1.append(cq); vs.append(v.T.copy()); as_.append(a.T.copy()); fs.append(f.T.copy())
+                Mup.append(np.triu(Mi_up)); Mdense.append(Mi); qdds.append(qdd); Us.append(U); Dinvs.append(Dinv)
+                dc0.append(g.test_rnea_grad(q[k], qd[k], None))
+                dc1.append(g.test_rnea_grad(q[k], qd[k], qdd))
+                dfs.append(g.test_fd_grad(q[k], qd[k], u[k]))
+        out.update(c_noqdd=np.array(c0), c_qdd=np.array(c1), v=np.array(vs), a=np.array(as_), f=np.array(fs),
+                   Minv_upper=np.array(Mup), Minv_dense=np.array(Mdense), qdd=np.array(qdds), U=np.array(Us),
+                   Dinv=np.array(Dinvs), dc_du_noqdd=np.array(dc0), dc_du_qdd=np.array(dc1), df_du=np.array(dfs))
+        # integer bookkeeping (helpers/_topology_helpers.py:193-215)
+        (dva, dva_per, rs_dva, df, df_per, rs_df, df_self) = g.gen_topology_sparsity_helpers_python()
+        (na, ns, rsa, rss) = g.gen_topology_sparsity_helpers_python(True)
+        out.update(dva_cols_per_partial=np.int64(dva), dva_cols_per_jid=np.array(dva_per), running_sum_dva_cols_per_jid=np.array(rs_dva),
+                   df_cols_per_partial=np.int64(df), df_cols_per_jid=np.array(df_per), running_sum_df_cols_per_jid=np.array(rs_df),
+                   df_col_that_is_jid=np.array(df_self), num_ancestors=np.array([int(x) for x in na]),
+                   num_subtree=np.array([int(x) for x in ns]), running_sum_num_ancestors=np.array([int(x) for x in rsa]),
+                   running_sum_num_subtree=np.array([int(x) for x in rss]),
+                   topology_helpers_size=np.int64(g.gen_topology_helpers_size()),
+                   parent_ids=np.array(robot.get_parent_id_array()),
+                   S_inds=np.array([robot.get_S_by_id(j).tolist().index(1) for j in range(n)]))
+        # size constants (GRiDCodeGenerator.py:70-83)
+        XI = 72 * n
+        sugg = min(32 * int(np.ceil(6 * 2 * dva / 32.0)), 512)
+        out["size_constants"] = np.array([
+            g.gen_inverse_dynamics_inner_temp_mem_size() + XI,
+            g.gen_direct_minv_inner_temp_mem_size() + XI,
+            g.gen_forward_dynamics_inner_temp_mem_size() + XI,
+            g.gen_inverse_dynamics_gradient_inner_temp_mem_size() + XI,
+            g.gen_forward_dynamics_gradient_inner_temp_mem_size() + XI,
+            int(g.gen_inverse_dynamics_gradient_kernel_max_temp_mem_size()) + XI,
+            int(g.gen_forward_dynamics_gradient_kernel_max_temp_mem_size()) + XI,
+            sugg], dtype=np.int64)
+        # model-constant tables as the reference would emit them (helpers/_topology_helpers.py:3-54, 217-258)
+        g.code_str = ""
+        g.indent_level = 0
+        g.gen_init_XImats()
+        out["h_XImats"] = parse_emitted_array(g.code_str, "h_XImats")
+        g.code_str = ""
+        g.gen_init_topology_helpers()
+        m = re.search(r"int h_topology_helpers\[\] = \{(.*?)\};", g.code_str, re.S)
+        if m:
+            body = re.sub(r"//[^\n]*", "", m.group(1))
+            out["h_topology_helpers"] = np.array([int(x) for x in body.replace("\n", " ").split(",") if x.strip()],
+                                                 dtype=np.int64)
+        else:
+            out["h_topology_helpers"] = np.zeros(0, dtype=np.int64)
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print("wrote", path, {k: np.asarray(v).shape for k, v in out.items() if k in ("df_du", "h_XImats", "h_topology_helpers")})
+
+
+if __name__ == "__main__":
+    main()
