@@ -1,0 +1,150 @@
+"""Generator facade: ``GRiDCodeGenerator(robot).gen_all_code()`` writes ``<FILE_NAMESPACE>.hip.h``.
+
+Drop-in boundary (reference GRiDCodeGenerator.py:37 and :241): same constructor arguments, same
+``gen_all_code(use_thread_group=False, include_base_inertia=False)`` entry point, output written to the
+current working directory and left in ``.code_str``; the emitted header exposes the same
+``ALGORITHM_inner / _device / _kernel / host`` names and buffer layouts.  What is emitted is HIP for
+gfx950 with one wavefront lane per configuration, not the reference's
+one-block-per-configuration CUDA.
+
+Generation-time knobs that have no reference counterpart are keyword-only:
+    precision        "fp32" | "fp64"  compute type C used for T=float (I/O stays T)
+    trig             "f32" | "f64"    sin/cos in float, or in double then rounded as the reference does
+    suggested_threads                 threads per block the LDS counts are sized for (multiple of 64)
+    out_chunk                         max values per configuration staged in LDS per coalesced flush
+    emit_order       "demand" | "creation"  ordering of the straight-line bodies
+    emit_inner_api                    also emit the pointer-style ``_inner`` tier (API parity)
+"""
+from .algorithms._emit import AlgorithmEmitMixin
+from .emit.model import RobotSpec
+from .helpers._runtime_emit import RuntimeEmitMixin
+from .helpers._text import TextMixin
+
+
+class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin):
+    def __init__(self, robotObj, DEBUG_MODE=False, NEED_PRINT_MAT=False, USE_DYNAMIC_SHARED_MEM=True,
+                 FILE_NAMESPACE="grid", *, precision="fp32", trig="f32", suggested_threads=64, max_threads=256,
+                 out_chunk=64, emit_order="demand", emit_inner_api=True, suggested_max_blocks=2048):
+        if precision not in ("fp32", "fp64"):
+            raise ValueError("precision must be 'fp32' or 'fp64'")
+        if trig not in ("f32", "f64"):
+            raise ValueError("trig must be 'f32' or 'f64'")
+        if suggested_threads % 64 != 0 or not (64 <= suggested_threads <= max_threads <= 1024):
+            raise ValueError("need 64 <= suggested_threads <= max_threads <= 1024, suggested_threads a multiple of 64")
+        self.robot = robotObj
+        self.spec = RobotSpec(robotObj)
+        self._chunks = []
+        self.indent_level = 0
+        self.DEBUG_MODE = DEBUG_MODE
+        self.gen_print_mat = DEBUG_MODE or NEED_PRINT_MAT
+        # kept for signature parity: the lane-per-configuration kernels always use dynamic LDS
+        self.use_dynamic_shared_mem_flag = True
+        self.file_namespace = FILE_NAMESPACE
+        self.precision = precision
+        self.trig = trig
+        self.suggested_threads = int(suggested_threads)
+        self.max_threads = int(max_threads)
+        self.suggested_max_blocks = int(suggested_max_blocks)
+        self.out_chunk = int(out_chunk)
+        self.emit_order = emit_order
+        self.emit_inner_api = bool(emit_inner_api)
+        self.core_stats = {}
+        self.trace_stats = {}
+        self._build_io_layout()
+
+    # reference-compatible integer bookkeeping (helpers/_topology_helpers.py:184-215)
+    def gen_topology_helpers_size(self):
+        return self.spec.topology_helpers_size()
+
+    def gen_topology_sparsity_helpers_python(self, INIT_MODE=False):
+        t = self.spec.sparsity_tables()
+        if INIT_MODE:
+            return ([str(v) for v in t["num_ancestors"]], [str(v) for v in t["num_subtree"]],
+                    [str(v) for v in t["running_sum_num_ancestors"]], [str(v) for v in t["running_sum_num_subtree"]])
+        return (t["dva_cols_per_partial"], t["dva_cols_per_jid"], t["running_sum_dva_cols_per_jid"],
+                t["df_cols_per_partial"], t["df_cols_per_jid"], t["running_sum_df_cols_per_jid"], t["df_col_that_is_jid"])
+
+    def output_file_name(self):
+        return self.file_namespace + ".hip.h"
+
+    def gen_all_code(self, use_thread_group=False, include_base_inertia=False):
+        if use_thread_group:
+            raise NotImplementedError("use_thread_group (cooperative groups) is an unfinished placeholder in the reference "
+                                      "(algorithms/_inverse_dynamics.py:391) and has no place in a lane-per-configuration design")
+        if include_base_inertia:
+            raise NotImplementedError("include_base_inertia adds data no reference emitter reads (helpers/_topology_helpers.py:5-12)")
+        self._chunks = []
+        self.indent_level = 0
+        self.core_stats = {}
+        self.trace_stats = {}
+        n = self.spec.n
+        file_notes = [
+            "Interface is:",
+            "    __host__   robotModel<T> *d_robotModel = init_robotModel<T>()",
+            "    __host__   hipStream_t *streams = init_grid<T>()",
+            "    __host__   gridData<T> *hd_data = init_gridData<T,NUM_TIMESTEPS>();",
+            "    __host__   close_grid<T>(hipStream_t *streams, robotModel<T> *d_robotModel, gridData<T> *hd_data)",
+            "",
+            "    __device__ inverse_dynamics_device<T>(T *s_c, const T *s_q, const T *s_qd, const robotModel<T> *d_robotModel, const T gravity)",
+            "    __device__ inverse_dynamics_device<T>(T *s_c, const T *s_q, const T *s_qd, const T *s_qdd, const robotModel<T> *d_robotModel, const T gravity)",
+            "    __global__ inverse_dynamics_kernel<T>(T *d_c, const T *d_q_qd, const int stride_q_qd, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS)",
+            "    __global__ inverse_dynamics_kernel<T>(T *d_c, const T *d_q_qd, const int stride_q_qd, const T *d_qdd, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS)",
+            "    __host__   inverse_dynamics<T,USE_QDD_FLAG=false,USE_COMPRESSED_MEM=false>(gridData<T> *hd_data, const robotModel<T> *d_robotModel, const T gravity, const int num_timesteps, const dim3 block_dimms, const dim3 thread_dimms, hipStream_t *streams)",
+            "",
+            "    __device__ inverse_dynamics_vaf_device<T>(T *s_vaf, const T *s_q, const T *s_qd, const robotModel<T> *d_robotModel, const T gravity)",
+            "    __device__ inverse_dynamics_vaf_device<T>(T *s_vaf, const T *s_q, const T *s_qd, const T *s_qdd, const robotModel<T> *d_robotModel, const T gravity)",
+            "",
+            "    __device__ direct_minv_device<T>(T *s_Minv, const T *s_q, const robotModel<T> *d_robotModel)",
+            "    __global__ direct_minv_kernel<T>(T *d_Minv, const T *d_q, const int stride_q, const robotModel<T> *d_robotModel, const int NUM_TIMESTEPS)",
+            "    __host__   direct_minv<T,USE_COMPRESSED_MEM=false>(gridData<T> *hd_data, const robotModel<T> *d_robotModel, const int num_timesteps, const dim3 block_dimms, const dim3 thread_dimms, hipStream_t *streams)",
+            "",
+            "    __device__ forward_dynamics_device<T>(T *s_qdd, const T *s_q, const T *s_qd, const T *s_u, const robotModel<T> *d_robotModel, const T gravity)",
+            "    __global__ forward_dynamics_kernel<T>(T *d_qdd, const T *d_q_qd_u, const int stride_q_qd_u, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS)",
+            "    __host__   forward_dynamics<T>(gridData<T> *hd_data, const robotModel<T> *d_robotModel, const T gravity, const int num_timesteps, const dim3 block_dimms, const dim3 thread_dimms, hipStream_t *streams)",
+            "",
+            "    __device__ inverse_dynamics_gradient_device<T>(T *s_dc_du, const T *s_q, const T *s_qd, const robotModel<T> *d_robotModel, const T gravity)",
+            "    __device__ inverse_dynamics_gradient_device<T>(T *s_dc_du, const T *s_q, const T *s_qd, const T *s_qdd, const robotModel<T> *d_robotModel, const T gravity)",
+            "    __global__ inverse_dynamics_gradient_kernel<T>(T *d_dc_du, const T *d_q_qd, const int stride_q_qd, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS)",
+            "    __global__ inverse_dynamics_gradient_kernel<T>(T *d_dc_du, const T *d_q_qd, const int stride_q_qd, const T *d_qdd, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS)",
+            "    __host__   inverse_dynamics_gradient<T,USE_QDD_FLAG=false,USE_COMPRESSED_MEM=false>(gridData<T> *hd_data, const robotModel<T> *d_robotModel, const T gravity, const int num_timesteps, const dim3 block_dimms, const dim3 thread_dimms, hipStream_t *streams)",
+            "",
+            "    __device__ forward_dynamics_gradient_device<T>(T *s_df_du, const T *s_q, const T *s_qd, const T *s_u, const robotModel<T> *d_robotModel, const T gravity)",
+            "    __device__ forward_dynamics_gradient_device<T>(T *s_df_du, const T *s_q, const T *s_qd, const T *s_qdd, const T *s_Minv, const robotModel<T> *d_robotModel, const T gravity)",
+            "    __global__ forward_dynamics_gradient_kernel<T>(T *d_df_du, const T *d_q_qd_u, const int stride_q_qd_u, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS)",
+            "    __global__ forward_dynamics_gradient_kernel<T>(T *d_df_du, const T *d_q_qd, const int stride_q_qd, const T *d_qdd, const T *d_Minv, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS)",
+            "    __host__   forward_dynamics_gradient<T,USE_QDD_MINV_FLAG=false>(gridData<T> *hd_data, const robotModel<T> *d_robotModel, const T gravity, const int num_timesteps, const dim3 block_dimms, const dim3 thread_dimms, hipStream_t *streams)",
+            "",
+            "Every host function also exists as <name>_compute_only(...) (device-resident I/O, no streams argument) and",
+            "<name>_launch(..., hipStream_t stream) (asynchronous, no synchronisation).",
+            "",
+            "Suggested Type T is float",
+            "",
+            "Execution model (differs from the CUDA reference): ONE WAVEFRONT LANE OWNS ONE CONFIGURATION.",
+            "    _inner / _device functions take LANE-PRIVATE arrays (registers after inlining), not block-shared memory;",
+            "    kernels process 64 consecutive configurations per wavefront and stage the AoS buffers through LDS so",
+            "    global loads/stores are coalesced; there is no __syncthreads on the compute path.",
+            "Launch kernels with <<<blocks, SUGGESTED_THREADS, <FUNC_CODE>_DYNAMIC_SHARED_MEM_COUNT*sizeof(T)>>> where <FUNC_CODE> = [ID, MINV, FD, ID_DU, FD_DU]",
+        ]
+        self.gen_add_func_doc("This instance of %s is optimized for the urdf: %s (%d joints), target gfx950 / wave64"
+                              % (self.output_file_name(), self.spec.name, n), file_notes)
+        self.gen_add_includes(use_thread_group)
+        self.gen_add_gpu_err()
+        self.gen_add_func_doc("All functions are kept in this namespace")
+        self.gen_add_code_line("namespace " + self.file_namespace + " {", True)
+        self.gen_add_constants_helpers()
+        self.gen_launch_helpers()
+        self.gen_lane_helpers()
+        self.gen_init_topology_helpers()
+        self.gen_init_XImats(include_base_inertia)
+        self.gen_init_robotModel()
+        self.gen_init_gridData()
+        self.gen_load_update_XImats_helpers(use_thread_group)
+        self.gen_inverse_dynamics(use_thread_group)
+        self.gen_direct_minv(use_thread_group)
+        self.gen_forward_dynamics(use_thread_group)
+        self.gen_inverse_dynamics_gradient(use_thread_group)
+        self.gen_forward_dynamics_gradient(use_thread_group)
+        self.gen_init_close_grid()
+        self.gen_add_end_control_flow()
+        with open(self.output_file_name(), "w") as fh:
+            fh.write(self.code_str)

@@ -1,1 +1,6 @@
-"""MI355X-native rigid-body-dynamics code generator (gfx950 / CDNA4, HIP, wave64)."""
+"""MI355X-native rigid-body-dynamics code generator (gfx950 / CDNA4, HIP, wave64).
+
+``from gridcodegenerator_amd import GRiDCodeGenerator`` mirrors the reference package import
+(reference ``__init__.py:1``).
+"""
+from .GRiDCodeGenerator import GRiDCodeGenerator  # noqa: F401

@@ -1,0 +1,541 @@
+"""Per-algorithm emission: ``gen_<alg>_inner / _device / _kernel / _host / gen_<alg>`` for
+inverse dynamics (RNEA), direct Minv, forward dynamics and the two analytical gradients.
+
+Public surface reproduced from the reference (same names / argument order / buffer layouts):
+    algorithms/_inverse_dynamics.py:311-495, _direct_minv.py:384-517, _forward_dynamics.py:114-252,
+    _inverse_dynamics_gradient.py:652-834, _forward_dynamics_gradient.py:59-242.
+What is emitted is different in kind: every ``_inner`` / core is one straight-line body for ONE lane
+(trace.py), ``_device`` wraps a fused core over lane-private arrays, ``_kernel`` adds the wave-level
+coalesced staging (helpers/_runtime_emit.py) and a grid-stride loop over 64-configuration tiles.
+"""
+from ..emit import cores
+
+MAX_IN_PIECE = 63   # inputs wider than this are staged through LDS in pieces (keeps LDS/wave small)
+
+
+def _largest_divisor_leq(n, cap):
+    for d in range(min(n, cap), 0, -1):
+        if n % d == 0:
+            return d
+    return 1
+
+
+class AlgorithmEmitMixin:
+    # ------------------------------------------------------------------------------------------
+    # layouts
+    # ------------------------------------------------------------------------------------------
+    def _build_io_layout(self):
+        n = self.spec.n
+        cap = self.out_chunk
+
+        def chunk(n_out):
+            return n_out if n_out <= cap else _largest_divisor_leq(n_out, cap)
+
+        def pieces(total):
+            return [min(MAX_IN_PIECE, total - o) for o in range(0, total, MAX_IN_PIECE)]
+
+        lay = {
+            "ID": dict(inputs=[("q_qd", 2 * n), ("qdd", n)], n_out=n),
+            "MINV": dict(inputs=[("q", n)], n_out=n * n),
+            "FD": dict(inputs=[("q_qd_u", 3 * n)], n_out=n),
+            "ID_DU": dict(inputs=[("q_qd", 2 * n), ("qdd", n)], n_out=2 * n * n),
+            "FD_DU": dict(inputs=[("q_qd_u", 3 * n), ("qdd", n), ("Minv", n * n)], n_out=2 * n * n),
+        }
+        for d in lay.values():
+            d["chunk"] = chunk(d["n_out"])
+            d["inputs"] = [(nm, p) for (nm, tot) in d["inputs"] for p in pieces(tot)]
+        self.io_layout = lay
+
+    # ------------------------------------------------------------------------------------------
+    # generic pieces
+    # ------------------------------------------------------------------------------------------
+    def _emit_traced_function(self, doc, notes, params, template, qualifiers, signature, tracer, store=None):
+        self.gen_add_func_doc(doc, notes, params, None)
+        self.gen_add_code_line(template)
+        self.gen_add_code_line(qualifiers)
+        self.gen_add_code_line(signature + " {", True)
+        ind = "    " * self.indent_level
+        lines = tracer.emit(indent=ind, order=self.emit_order, store=store)
+        self.gen_add_raw("\n".join(lines))
+        self.gen_add_end_function()
+        self.trace_stats[signature.split("(")[0].split()[-1] + "/" + str(len(self.trace_stats))] = tracer.op_counts()
+
+    def _emit_core(self, name, doc, tracer):
+        """template <T, C, In, Out> void name(const In &in, Out &out, const T gravity)."""
+        self.core_stats[name] = dict(tracer.op_counts(), flops=tracer.flops())
+        self._emit_traced_function(
+            doc, ["straight-line body for ONE configuration (one wavefront lane); compute type C, storage type T",
+                  "in: accessor with q(i), qd(i), u(i), qdd(i), Minv(i); out: sink with put(i, value), i increasing"],
+            ["in input accessor", "out output sink", "gravity is the gravity constant"],
+            "template <typename T, typename C, typename In, typename Out>",
+            "__host__ __device__ __forceinline__",
+            "void %s(const In &in, Out &out, const T gravity)" % name, tracer,
+            store=lambda dst, val: "out.put(%s, (T)(%s));" % (dst, val))
+
+    def _emit_load(self, dst, src, total, stride):
+        off = 0
+        while off < total:
+            p = min(MAX_IN_PIECE, total - off)
+            self.gen_add_code_line("grid_load_tile<T,%d,%d>(%s + %d, %s + %d, %s, k0, it.lane, NUM_TIMESTEPS, s_wave, it.staged);"
+                                   % (p, self._pad(p), dst, off, src, off, stride))
+            off += p
+
+    def _emit_kernel(self, alg, name, core, doc, out_name, primary, extras, has_gravity, accessor):
+        """primary = (buffer name, count, stride variable); extras = [(buffer name, count)] with row stride = count."""
+        n_out = self.io_layout[alg]["n_out"]
+        ch = self.io_layout[alg]["chunk"]
+        pname, pcount, pstride = primary
+        sig = "void %s(T *d_%s, const T *d_%s, const int %s, " % (name, out_name, pname, pstride)
+        for (ename, _) in extras:
+            sig += "const T *d_%s, " % ename
+        sig += "const robotModel<T> *d_robotModel, " + ("const T gravity, " if has_gravity else "") + "const int NUM_TIMESTEPS)"
+        params = ["d_%s is the output buffer, %d values per configuration" % (out_name, n_out),
+                  "d_%s is the input buffer, %d values read per configuration" % (pname, pcount),
+                  "%s is the stride between configurations in d_%s" % (pstride, pname)]
+        params += ["d_%s holds %d values per configuration (dense)" % (en, ec) for (en, ec) in extras]
+        params += ["d_robotModel is the pointer to the initialized model specific helpers on the GPU (unused: constants are baked in)"]
+        if has_gravity:
+            params.append("gravity is the gravity constant")
+        params.append("NUM_TIMESTEPS is the number of configurations")
+        self.gen_add_func_doc(doc, ["lane-per-configuration: each wavefront owns 64 consecutive configurations per tile",
+                                    "launch with <<<blocks, SUGGESTED_THREADS, %s_DYNAMIC_SHARED_MEM_COUNT*sizeof(T)>>>; any block shape up to"
+                                    % alg, "GRID_MAX_THREADS threads is accepted (shapes that are not whole waves fall back to unstaged I/O)"],
+                              params, None)
+        self.gen_add_code_line("template <typename T, typename C = typename grid_compute<T>::type>")
+        self.gen_add_code_line("__global__ __launch_bounds__(GRID_MAX_THREADS)")
+        self.gen_add_code_line(sig + " {", True)
+        self.gen_add_code_lines([
+            "extern __shared__ __align__(16) unsigned char s_grid_dyn[];",
+            "const grid_tile_iter it;",
+            "T *s_wave = reinterpret_cast<T *>(s_grid_dyn) + it.wave_in_block*%d;" % self.lds_per_wave(alg),
+            "for (int k0 = it.k0_first; k0 < NUM_TIMESTEPS; k0 += it.k0_step){",
+        ])
+        self.indent_level += 1
+        self.gen_add_code_line("T s_%s[%d];" % (pname, pcount))
+        self._emit_load("s_" + pname, "d_" + pname, pcount, pstride)
+        for (ename, ecount) in extras:
+            self.gen_add_code_line("T s_%s[%d];" % (ename, ecount))
+            self._emit_load("s_" + ename, "d_" + ename, ecount, str(ecount))
+        self.gen_add_code_line("const grid_in_ptrs<T> in = {%s};" % accessor)
+        self.gen_add_code_line("grid_out_staged<T,%d,%d,%d> out = {s_wave, d_%s, k0, it.lane, NUM_TIMESTEPS, it.staged};"
+                               % (n_out, ch, self._pad(ch), out_name))
+        self.gen_add_code_line("%s<T,C>(in, out, %s);" % (core, "gravity" if has_gravity else "static_cast<T>(0)"))
+        self.gen_add_end_control_flow()
+        self.gen_add_end_function()
+
+    def _emit_host(self, alg, name, doc, template, has_gravity, body_pre, launches, body_post, timing_label):
+        """Host wrappers: mode 0 (copies + launch, reference semantics), _compute_only (mode 2) and an
+        asynchronous _launch extension (explicit stream, no synchronisation) used by the C-ABI shim."""
+        grav = "const T gravity, " if has_gravity else ""
+        for mode in ("full", "compute_only", "launch"):
+            suffix = {"full": "", "compute_only": "_compute_only", "launch": "_launch"}[mode]
+            tail = {"full": ", hipStream_t *streams", "compute_only": "", "launch": ", hipStream_t stream"}[mode]
+            notes = {"full": ["H2D copy of the inputs, kernel, D2H copy of the result, synchronous (reference mode 0)"],
+                     "compute_only": ["inputs/outputs already on the device (reference mode 2: _compute_only), synchronous"],
+                     "launch": ["MI355X extension: asynchronous launch on `stream`, no copies, no synchronisation",
+                                "(graph-capturable; used by the C-ABI and for multi-GPU sharding on independent streams)"]}[mode]
+            self.gen_add_func_doc(doc, notes, ["hd_data is the packaged input and output pointers",
+                                               "d_robotModel is the pointer to the initialized model specific helpers on the GPU",
+                                               "num_timesteps is the number of configurations",
+                                               "block_dimms / thread_dimms: launch shape; illegal shapes are replaced by the suggested one"], None)
+            self.gen_add_code_line(template)
+            self.gen_add_code_line("__host__")
+            self.gen_add_code_line("void %s%s(gridData<T> *hd_data, const robotModel<T> *d_robotModel, %sconst int num_timesteps," % (name, suffix, grav))
+            self.gen_add_code_line("        const dim3 block_dimms, const dim3 thread_dimms%s) {" % tail, True)
+            self.gen_add_code_line("dim3 blocks, threads; grid_launch_dims(block_dimms, thread_dimms, num_timesteps, &blocks, &threads);")
+            self.gen_add_code_line("const size_t lds_bytes = grid_lds_bytes<T>(threads, %d);" % self.lds_per_wave(alg))
+            stream = {"full": "streams[0]", "compute_only": "0", "launch": "stream"}[mode]
+            for line in body_pre(mode):
+                self.gen_add_code_line(line)
+            if mode == "full":
+                self.gen_add_code_line("gpuErrchk(hipDeviceSynchronize());")
+            self.gen_add_code_line("// then call the kernel")
+            for line in launches:
+                self.gen_add_code_line(line.replace("@L", "<<<blocks,threads,lds_bytes,%s>>>" % stream))
+            self.gen_add_code_line("gpuErrchk(hipGetLastError());")
+            if mode != "launch":
+                self.gen_add_code_line("gpuErrchk(hipDeviceSynchronize());")
+            if mode == "full":
+                for line in body_post:
+                    self.gen_add_code_line(line)
+            self.gen_add_end_function()
+
+    def gen_launch_helpers(self):
+        self.gen_add_code_lines([
+            "const int GRID_MAX_THREADS = %d; // __launch_bounds__ of every kernel: <= 1 wave per SIMD keeps the full VGPR file" % self.max_threads,
+            "/** Sanitise a launch shape: shapes the kernels cannot run (0 or > GRID_MAX_THREADS threads) become the suggested one. */",
+            "__host__ inline",
+            "void grid_launch_dims(const dim3 block_dimms, const dim3 thread_dimms, const int num_timesteps, dim3 *blocks, dim3 *threads){",
+            "    const unsigned long long nthreads = (unsigned long long)thread_dimms.x*thread_dimms.y*thread_dimms.z;",
+            "    const unsigned long long nblocks = (unsigned long long)block_dimms.x*block_dimms.y*block_dimms.z;",
+            "    if (nthreads == 0 || nthreads > (unsigned long long)GRID_MAX_THREADS || nblocks == 0){",
+            "        int b = (num_timesteps + SUGGESTED_THREADS - 1)/SUGGESTED_THREADS; if (b > SUGGESTED_MAX_BLOCKS){b = SUGGESTED_MAX_BLOCKS;} if (b < 1){b = 1;}",
+            "        *blocks = dim3(b,1,1); *threads = dim3(SUGGESTED_THREADS,1,1);",
+            "    }",
+            "    else {*blocks = block_dimms; *threads = thread_dimms;}",
+            "}",
+            "/** Dynamic LDS bytes for a block of `threads` (whole waves; 0 if the kernel will run unstaged). */",
+            "template <typename T>",
+            "__host__ inline",
+            "size_t grid_lds_bytes(const dim3 threads, const int elems_per_wave){",
+            "    const int nthreads = threads.x*threads.y*threads.z;",
+            "    if ((nthreads % GRID_WAVE_SIZE) != 0 || nthreads > SUGGESTED_THREADS){return 0;}",
+            "    return (size_t)(nthreads/GRID_WAVE_SIZE)*elems_per_wave*sizeof(T);",
+            "}",
+            "",
+        ])
+
+    # ------------------------------------------------------------------------------------------
+    # load_update_XImats_helpers (lane-private sin/cos table)
+    # ------------------------------------------------------------------------------------------
+    def gen_load_update_XImats_helpers_temp_mem_size(self):
+        return 0
+
+    def gen_load_update_XImats_helpers(self, use_thread_group=False):
+        n = self.spec.n
+        self.gen_add_func_doc("Updates the lane-private X(q) cache according to the configuration",
+                              ["The reference copies 72n model constants to shared memory and patches the theta-dependent",
+                               "entries (helpers/_topology_helpers.py:90-182).  Here the constants live in the instruction stream,",
+                               "so all that depends on q is sin/cos: s_XImats[j] = sin(q_j), s_XImats[NUM_JOINTS + j] = cos(q_j)."],
+                              ["s_XImats is the lane-private destination of size XIMATS_LANE_COUNT = " + str(2 * n),
+                               "s_q is the lane-private vector of joint positions",
+                               "d_robotModel is unused (API parity)", "s_temp is unused (API parity; may be nullptr)"], None)
+        self.gen_add_code_lines(["template <typename T>", "__host__ __device__ __forceinline__",
+                                 "void load_update_XImats_helpers(T *s_XImats, const T *s_q, const robotModel<T> *d_robotModel, T *s_temp) {"], True)
+        self.gen_add_code_line("(void)d_robotModel; (void)s_temp;")
+        for j in range(n):
+            if self.spec.uses_trig[j]:
+                self.gen_add_code_line("{typename grid_compute<T>::type s, c; grid_sincos((typename grid_compute<T>::type)s_q[%d], &s, &c); "
+                                       "s_XImats[%d] = (T)s; s_XImats[%d] = (T)c;}" % (j, j, n + j))
+            else:
+                self.gen_add_code_line("s_XImats[%d] = static_cast<T>(0); s_XImats[%d] = static_cast<T>(1);" % (j, n + j))
+        self.gen_add_end_function()
+
+    # ------------------------------------------------------------------------------------------
+    # inverse dynamics
+    # ------------------------------------------------------------------------------------------
+    def gen_inverse_dynamics_inner_temp_mem_size(self):
+        return 0
+
+    def gen_inverse_dynamics_inner(self, use_thread_group=False, compute_c=True, use_qdd_input=True):
+        tr = cores.inner_inverse_dynamics(self.spec, compute_c, use_qdd_input)
+        name = "inverse_dynamics_inner" if compute_c else "inverse_dynamics_inner_vaf"
+        sig = "void %s(%sT *s_vaf, const T *s_q, const T *s_qd, %sT *s_XImats, T *s_temp, const T gravity)" % (
+            name, "T *s_c,  " if compute_c else "", "const T *s_qdd, " if use_qdd_input else "")
+        self._emit_traced_function("Compute the RNEA (Recursive Newton-Euler Algorithm)",
+                                   ([] if use_qdd_input else ["optimized for qdd = 0"]) + ["lane-private pointers; s_temp unused"],
+                                   ["s_vaf receives v, a, f (18*NUM_JOINTS)", "s_XImats is the lane-private sin/cos table"],
+                                   "template <typename T, typename C = typename grid_compute<T>::type>",
+                                   "__host__ __device__ __forceinline__", sig, tr)
+
+    def gen_inverse_dynamics_device(self, use_thread_group=False, compute_c=True, use_qdd_input=True):
+        n = self.spec.n
+        name = "inverse_dynamics_device" if compute_c else "inverse_dynamics_vaf_device"
+        core = ("inverse_dynamics_core" if compute_c else "inverse_dynamics_vaf_core") + ("_qdd" if use_qdd_input else "")
+        out = "s_c" if compute_c else "s_vaf"
+        sig = "void %s(T *%s, const T *s_q, const T *s_qd, %sconst robotModel<T> *d_robotModel, const T gravity)" % (
+            name, out, "const T *s_qdd, " if use_qdd_input else "")
+        self.gen_add_func_doc("Compute the RNEA (Recursive Newton-Euler Algorithm)",
+                              ["lane-private arrays in, lane-private array out"], [], None)
+        self.gen_add_code_lines(["template <typename T, typename C = typename grid_compute<T>::type>",
+                                 "__host__ __device__ __forceinline__", sig + " {"], True)
+        self.gen_add_code_lines(["(void)d_robotModel;",
+                                 "const grid_in_ptrs<T> in = {s_q, s_qd, nullptr, %s, nullptr};" % ("s_qdd" if use_qdd_input else "nullptr"),
+                                 "grid_out_ptr<T> out = {%s};" % out,
+                                 "%s<T,C>(in, out, gravity);" % core])
+        self.gen_add_end_function()
+
+    def gen_inverse_dynamics_kernel(self, use_thread_group=False, use_qdd_input=False, single_call_timing=False):
+        n = self.spec.n
+        self._emit_kernel("ID", "inverse_dynamics_kernel", "inverse_dynamics_core" + ("_qdd" if use_qdd_input else ""),
+                          "Compute the RNEA (Recursive Newton-Euler Algorithm)", "c", ("q_qd", 2 * n, "stride_q_qd"),
+                          [("qdd", n)] if use_qdd_input else [], True,
+                          "s_q_qd, s_q_qd + %d, nullptr, %s, nullptr" % (n, "s_qdd" if use_qdd_input else "nullptr"))
+
+    def gen_inverse_dynamics_host(self, mode=0):
+        def pre(mode):
+            if mode == "full":
+                return ["int stride_q_qd;",
+                        "if (USE_COMPRESSED_MEM) {stride_q_qd = 2*NUM_JOINTS; gpuErrchk(hipMemcpyAsync(hd_data->d_q_qd,hd_data->h_q_qd,stride_q_qd*num_timesteps*sizeof(T),hipMemcpyHostToDevice,streams[0]));}",
+                        "else {stride_q_qd = 3*NUM_JOINTS; gpuErrchk(hipMemcpyAsync(hd_data->d_q_qd_u,hd_data->h_q_qd_u,stride_q_qd*num_timesteps*sizeof(T),hipMemcpyHostToDevice,streams[0]));}",
+                        "if (USE_QDD_FLAG) {gpuErrchk(hipMemcpyAsync(hd_data->d_qdd,hd_data->h_qdd,NUM_JOINTS*num_timesteps*sizeof(T),hipMemcpyHostToDevice,streams[1]));}"]
+            return ["const int stride_q_qd = USE_COMPRESSED_MEM ? 2*NUM_JOINTS: 3*NUM_JOINTS;"]
+        launches = [
+            "const T *d_in = USE_COMPRESSED_MEM ? hd_data->d_q_qd : hd_data->d_q_qd_u;",
+            "if (USE_QDD_FLAG) {inverse_dynamics_kernel<T>@L(hd_data->d_c,d_in,stride_q_qd,hd_data->d_qdd,d_robotModel,gravity,num_timesteps);}",
+            "else              {inverse_dynamics_kernel<T>@L(hd_data->d_c,d_in,stride_q_qd,d_robotModel,gravity,num_timesteps);}"]
+        post = ["// finally transfer the result back",
+                "gpuErrchk(hipMemcpy(hd_data->h_c,hd_data->d_c,NUM_JOINTS*num_timesteps*sizeof(T),hipMemcpyDeviceToHost));",
+                "gpuErrchk(hipDeviceSynchronize());"]
+        self._emit_host("ID", "inverse_dynamics", "Compute the RNEA (Recursive Newton-Euler Algorithm)",
+                        "template <typename T, bool USE_QDD_FLAG = false, bool USE_COMPRESSED_MEM = false>", True, pre, launches, post, "ID")
+
+    def gen_inverse_dynamics(self, use_thread_group=False):
+        for use_qdd in (True, False):
+            self._emit_core("inverse_dynamics_core" + ("_qdd" if use_qdd else ""),
+                            "RNEA core: c = ID(q, qd%s)" % (", qdd" if use_qdd else ", 0"),
+                            cores.core_inverse_dynamics(self.spec, use_qdd))
+            self._emit_core("inverse_dynamics_vaf_core" + ("_qdd" if use_qdd else ""),
+                            "RNEA core returning v, a, f (18*NUM_JOINTS values: v | a | f, 6 per joint)",
+                            cores.core_inverse_dynamics_vaf(self.spec, use_qdd))
+        if self.emit_inner_api:
+            for compute_c in (True, False):
+                for use_qdd in (True, False):
+                    self.gen_inverse_dynamics_inner(use_thread_group, compute_c, use_qdd)
+        for compute_c in (True, False):
+            for use_qdd in (True, False):
+                self.gen_inverse_dynamics_device(use_thread_group, compute_c, use_qdd)
+        self.gen_inverse_dynamics_kernel(use_thread_group, True)
+        self.gen_inverse_dynamics_kernel(use_thread_group, False)
+        self.gen_inverse_dynamics_host()
+
+    # ------------------------------------------------------------------------------------------
+    # direct Minv
+    # ------------------------------------------------------------------------------------------
+    def gen_direct_minv_inner_temp_mem_size(self):
+        return 0
+
+    def gen_direct_minv_inner(self, use_thread_group=False):
+        self._emit_traced_function("Compute the inverse of the mass matrix",
+                                   ["Outputs a SYMMETRIC_UPPER triangular matrix for Minv (lower half written as 0)",
+                                    "lane-private pointers; s_temp unused"],
+                                   ["s_Minv is a pointer to memory for the final result (NUM_JOINTS^2, column-major)"],
+                                   "template <typename T, typename C = typename grid_compute<T>::type>",
+                                   "__host__ __device__ __forceinline__",
+                                   "void direct_minv_inner(T *s_Minv, const T *s_q, T *s_XImats, T *s_temp)",
+                                   cores.inner_direct_minv(self.spec))
+
+    def gen_direct_minv_device(self, use_thread_group=False):
+        self.gen_add_func_doc("Compute the inverse of the mass matrix", ["Outputs a SYMMETRIC_UPPER triangular matrix for Minv"], [], None)
+        self.gen_add_code_lines(["template <typename T, typename C = typename grid_compute<T>::type>",
+                                 "__host__ __device__ __forceinline__",
+                                 "void direct_minv_device(T *s_Minv, const T *s_q, const robotModel<T> *d_robotModel){"], True)
+        self.gen_add_code_lines(["(void)d_robotModel;",
+                                 "const grid_in_ptrs<T> in = {s_q, nullptr, nullptr, nullptr, nullptr};",
+                                 "grid_out_ptr<T> out = {s_Minv};",
+                                 "direct_minv_core<T,C>(in, out, static_cast<T>(0));"])
+        self.gen_add_end_function()
+
+    def gen_direct_minv_kernel(self, use_thread_group=False, single_call_timing=False):
+        n = self.spec.n
+        self._emit_kernel("MINV", "direct_minv_kernel", "direct_minv_core", "Compute the inverse of the mass matrix",
+                          "Minv", ("q", n, "stride_q"), [], False, "s_q, nullptr, nullptr, nullptr, nullptr")
+
+    def gen_direct_minv_host(self, mode=0):
+        def pre(mode):
+            if mode == "full":
+                return ["int stride_q;",
+                        "if (USE_COMPRESSED_MEM) {stride_q = NUM_JOINTS; gpuErrchk(hipMemcpyAsync(hd_data->d_q,hd_data->h_q,stride_q*num_timesteps*sizeof(T),hipMemcpyHostToDevice,streams[0]));}",
+                        "else {stride_q = 3*NUM_JOINTS; gpuErrchk(hipMemcpyAsync(hd_data->d_q_qd_u,hd_data->h_q_qd_u,stride_q*num_timesteps*sizeof(T),hipMemcpyHostToDevice,streams[0]));}"]
+            return ["const int stride_q = USE_COMPRESSED_MEM ? NUM_JOINTS: 3*NUM_JOINTS;"]
+        launches = ["direct_minv_kernel<T>@L(hd_data->d_Minv,USE_COMPRESSED_MEM ? hd_data->d_q : hd_data->d_q_qd_u,stride_q,d_robotModel,num_timesteps);"]
+        post = ["// finally transfer the result back",
+                "gpuErrchk(hipMemcpy(hd_data->h_Minv,hd_data->d_Minv,NUM_JOINTS*NUM_JOINTS*num_timesteps*sizeof(T),hipMemcpyDeviceToHost));",
+                "gpuErrchk(hipDeviceSynchronize());"]
+        self._emit_host("MINV", "direct_minv", "Compute the inverse of the mass matrix",
+                        "template <typename T, bool USE_COMPRESSED_MEM = false>", False, pre, launches, post, "Minv")
+
+    def gen_direct_minv(self, use_thread_group=False):
+        self._emit_core("direct_minv_core", "Direct (Carpentier) inverse of the joint-space inertia matrix, upper triangle",
+                        cores.core_direct_minv(self.spec))
+        if self.emit_inner_api:
+            self.gen_direct_minv_inner(use_thread_group)
+        self.gen_direct_minv_device(use_thread_group)
+        self.gen_direct_minv_kernel(use_thread_group)
+        self.gen_direct_minv_host()
+
+    # ------------------------------------------------------------------------------------------
+    # forward dynamics
+    # ------------------------------------------------------------------------------------------
+    def gen_forward_dynamics_inner_temp_mem_size(self):
+        return 0
+
+    def gen_forward_dynamics_finish(self, use_thread_group=False):
+        self._emit_traced_function("Finish the forward dynamics computation with qdd = Minv*(u-c)", [],
+                                   ["s_qdd is a pointer to memory for the final result", "s_u is the vector of joint input torques",
+                                    "s_c is the bias vector", "s_Minv is the (upper triangular, column-major) inverse mass matrix"],
+                                   "template <typename T, typename C = typename grid_compute<T>::type>",
+                                   "__host__ __device__ __forceinline__",
+                                   "void forward_dynamics_finish(T *s_qdd, const T *s_u, const T *s_c, const T *s_Minv)",
+                                   cores.inner_forward_dynamics_finish(self.spec))
+
+    def gen_forward_dynamics_inner(self, use_thread_group=False):
+        self._emit_traced_function("Computes forward dynamics", ["lane-private pointers; s_temp unused"],
+                                   ["s_qdd is a pointer to memory for the final result"],
+                                   "template <typename T, typename C = typename grid_compute<T>::type>",
+                                   "__host__ __device__ __forceinline__",
+                                   "void forward_dynamics_inner(T *s_qdd, const T *s_q, const T *s_qd, const T *s_u, T *s_XImats, T *s_temp, const T gravity)",
+                                   cores.inner_forward_dynamics(self.spec))
+
+    def gen_forward_dynamics_device(self, use_thread_group=False):
+        self.gen_add_func_doc("Computes forward dynamics", [], [], None)
+        self.gen_add_code_lines(["template <typename T, typename C = typename grid_compute<T>::type>",
+                                 "__host__ __device__ __forceinline__",
+                                 "void forward_dynamics_device(T *s_qdd, const T *s_q, const T *s_qd, const T *s_u, const robotModel<T> *d_robotModel, const T gravity) {"], True)
+        self.gen_add_code_lines(["(void)d_robotModel;",
+                                 "const grid_in_ptrs<T> in = {s_q, s_qd, s_u, nullptr, nullptr};",
+                                 "grid_out_ptr<T> out = {s_qdd};",
+                                 "forward_dynamics_core<T,C>(in, out, gravity);"])
+        self.gen_add_end_function()
+
+    def gen_forward_dynamics_kernel(self, use_thread_group=False, single_call_timing=False):
+        n = self.spec.n
+        self._emit_kernel("FD", "forward_dynamics_kernel", "forward_dynamics_core", "Computes forward dynamics",
+                          "qdd", ("q_qd_u", 3 * n, "stride_q_qd_u"), [], True,
+                          "s_q_qd_u, s_q_qd_u + %d, s_q_qd_u + %d, nullptr, nullptr" % (n, 2 * n))
+
+    def gen_forward_dynamics_host(self, mode=0):
+        def pre(mode):
+            lines = ["const int stride_q_qd_u = 3*NUM_JOINTS;"]
+            if mode == "full":
+                lines.append("gpuErrchk(hipMemcpyAsync(hd_data->d_q_qd_u,hd_data->h_q_qd_u,stride_q_qd_u*num_timesteps*sizeof(T),hipMemcpyHostToDevice,streams[0]));")
+            return lines
+        launches = ["forward_dynamics_kernel<T>@L(hd_data->d_qdd,hd_data->d_q_qd_u,stride_q_qd_u,d_robotModel,gravity,num_timesteps);"]
+        post = ["// finally transfer the result back",
+                "gpuErrchk(hipMemcpy(hd_data->h_qdd,hd_data->d_qdd,NUM_JOINTS*num_timesteps*sizeof(T),hipMemcpyDeviceToHost));",
+                "gpuErrchk(hipDeviceSynchronize());"]
+        self._emit_host("FD", "forward_dynamics", "Computes forward dynamics", "template <typename T>", True, pre, launches, post, "FD")
+
+    def gen_forward_dynamics(self, use_thread_group=False):
+        self._emit_core("forward_dynamics_core", "Forward dynamics core: qdd = Minv(q) (u - c(q, qd))",
+                        cores.core_forward_dynamics(self.spec))
+        if self.emit_inner_api:
+            self.gen_forward_dynamics_finish(use_thread_group)
+            self.gen_forward_dynamics_inner(use_thread_group)
+        self.gen_forward_dynamics_device(use_thread_group)
+        self.gen_forward_dynamics_kernel(use_thread_group)
+        self.gen_forward_dynamics_host()
+
+    # ------------------------------------------------------------------------------------------
+    # inverse dynamics gradient
+    # ------------------------------------------------------------------------------------------
+    def gen_inverse_dynamics_gradient_inner_temp_mem_size(self):
+        return 0
+
+    def gen_inverse_dynamics_gradient_kernel_max_temp_mem_size(self):
+        return 0
+
+    def gen_inverse_dynamics_gradient_inner(self, use_thread_group=False):
+        self._emit_traced_function("Computes the gradient of inverse dynamics",
+                                   ["Uses the precomputed v, a, f in s_vaf (f accumulated over subtrees)", "lane-private pointers; s_temp unused"],
+                                   ["s_dc_du is a pointer to memory for the final result of size 2*NUM_JOINTS*NUM_JOINTS"],
+                                   "template <typename T, typename C = typename grid_compute<T>::type>",
+                                   "__host__ __device__ __forceinline__",
+                                   "void inverse_dynamics_gradient_inner(T *s_dc_du, const T *s_q, const T *s_qd, const T *s_vaf, T *s_XImats, T *s_temp, const T gravity)",
+                                   cores.inner_inverse_dynamics_gradient(self.spec))
+
+    def gen_inverse_dynamics_gradient_device(self, use_thread_group=False, use_qdd_input=False):
+        self.gen_add_func_doc("Computes the gradient of inverse dynamics", [] if use_qdd_input else ["optimized for qdd = 0"], [], None)
+        self.gen_add_code_lines(["template <typename T, typename C = typename grid_compute<T>::type>",
+                                 "__host__ __device__ __forceinline__",
+                                 "void inverse_dynamics_gradient_device(T *s_dc_du, const T *s_q, const T *s_qd, %sconst robotModel<T> *d_robotModel, const T gravity) {"
+                                 % ("const T *s_qdd, " if use_qdd_input else "")], True)
+        self.gen_add_code_lines(["(void)d_robotModel;",
+                                 "const grid_in_ptrs<T> in = {s_q, s_qd, nullptr, %s, nullptr};" % ("s_qdd" if use_qdd_input else "nullptr"),
+                                 "grid_out_ptr<T> out = {s_dc_du};",
+                                 "inverse_dynamics_gradient_core%s<T,C>(in, out, gravity);" % ("_qdd" if use_qdd_input else "")])
+        self.gen_add_end_function()
+
+    def gen_inverse_dynamics_gradient_kernel(self, use_thread_group=False, use_qdd_input=False, single_call_timing=False):
+        n = self.spec.n
+        self._emit_kernel("ID_DU", "inverse_dynamics_gradient_kernel", "inverse_dynamics_gradient_core" + ("_qdd" if use_qdd_input else ""),
+                          "Computes the gradient of inverse dynamics", "dc_du", ("q_qd", 2 * n, "stride_q_qd"),
+                          [("qdd", n)] if use_qdd_input else [], True,
+                          "s_q_qd, s_q_qd + %d, nullptr, %s, nullptr" % (n, "s_qdd" if use_qdd_input else "nullptr"))
+
+    def gen_inverse_dynamics_gradient_host(self, mode=0):
+        def pre(mode):
+            if mode == "full":
+                return ["int stride_q_qd;",
+                        "if (USE_COMPRESSED_MEM) {stride_q_qd = 2*NUM_JOINTS; gpuErrchk(hipMemcpyAsync(hd_data->d_q_qd,hd_data->h_q_qd,stride_q_qd*num_timesteps*sizeof(T),hipMemcpyHostToDevice,streams[0]));}",
+                        "else {stride_q_qd = 3*NUM_JOINTS; gpuErrchk(hipMemcpyAsync(hd_data->d_q_qd_u,hd_data->h_q_qd_u,stride_q_qd*num_timesteps*sizeof(T),hipMemcpyHostToDevice,streams[0]));}",
+                        "if (USE_QDD_FLAG) {gpuErrchk(hipMemcpyAsync(hd_data->d_qdd,hd_data->h_qdd,NUM_JOINTS*num_timesteps*sizeof(T),hipMemcpyHostToDevice,streams[1]));}"]
+            return ["const int stride_q_qd = USE_COMPRESSED_MEM ? 2*NUM_JOINTS: 3*NUM_JOINTS;"]
+        launches = [
+            "const T *d_in = USE_COMPRESSED_MEM ? hd_data->d_q_qd : hd_data->d_q_qd_u;",
+            "if (USE_QDD_FLAG) {inverse_dynamics_gradient_kernel<T>@L(hd_data->d_dc_du,d_in,stride_q_qd,hd_data->d_qdd,d_robotModel,gravity,num_timesteps);}",
+            "else              {inverse_dynamics_gradient_kernel<T>@L(hd_data->d_dc_du,d_in,stride_q_qd,d_robotModel,gravity,num_timesteps);}"]
+        post = ["// finally transfer the result back",
+                "gpuErrchk(hipMemcpy(hd_data->h_dc_du,hd_data->d_dc_du,NUM_JOINTS*2*NUM_JOINTS*num_timesteps*sizeof(T),hipMemcpyDeviceToHost));",
+                "gpuErrchk(hipDeviceSynchronize());"]
+        self._emit_host("ID_DU", "inverse_dynamics_gradient", "Computes the gradient of inverse dynamics",
+                        "template <typename T, bool USE_QDD_FLAG = false, bool USE_COMPRESSED_MEM = false>", True, pre, launches, post, "ID_DU")
+
+    def gen_inverse_dynamics_gradient(self, use_thread_group=False):
+        for use_qdd in (True, False):
+            self._emit_core("inverse_dynamics_gradient_core" + ("_qdd" if use_qdd else ""),
+                            "RNEA + analytical gradient core: dc_du = [dc/dq | dc/dqd] at (q, qd%s)" % (", qdd" if use_qdd else ", 0"),
+                            cores.core_inverse_dynamics_gradient(self.spec, use_qdd))
+        if self.emit_inner_api:
+            self.gen_inverse_dynamics_gradient_inner(use_thread_group)
+        self.gen_inverse_dynamics_gradient_device(use_thread_group, False)
+        self.gen_inverse_dynamics_gradient_device(use_thread_group, True)
+        self.gen_inverse_dynamics_gradient_kernel(use_thread_group, True)
+        self.gen_inverse_dynamics_gradient_kernel(use_thread_group, False)
+        self.gen_inverse_dynamics_gradient_host()
+
+    # ------------------------------------------------------------------------------------------
+    # forward dynamics gradient (headline)
+    # ------------------------------------------------------------------------------------------
+    def gen_forward_dynamics_gradient_inner_temp_mem_size(self, use_qdd_Minv_input=False):
+        return 0
+
+    def gen_forward_dynamics_gradient_kernel_max_temp_mem_size(self):
+        return 0
+
+    def gen_forward_dynamics_gradient_device(self, use_thread_group=False, use_qdd_Minv_input=False):
+        notes = ["Uses the fd/du = -Minv*id/du trick as described in Carpentier and Mansrud 'Analytical Derivatives of Rigid Body Dynamics Algorithms'"]
+        self.gen_add_func_doc("Computes the gradient of forward dynamics", notes, [], None)
+        extra = "const T *s_qdd, const T *s_Minv, " if use_qdd_Minv_input else "const T *s_u, "
+        self.gen_add_code_lines(["template <typename T, typename C = typename grid_compute<T>::type>",
+                                 "__host__ __device__ __forceinline__",
+                                 "void forward_dynamics_gradient_device(T *s_df_du, const T *s_q, const T *s_qd, %sconst robotModel<T> *d_robotModel, const T gravity) {" % extra], True)
+        acc = "s_q, s_qd, nullptr, s_qdd, s_Minv" if use_qdd_Minv_input else "s_q, s_qd, s_u, nullptr, nullptr"
+        self.gen_add_code_lines(["(void)d_robotModel;",
+                                 "const grid_in_ptrs<T> in = {%s};" % acc,
+                                 "grid_out_ptr<T> out = {s_df_du};",
+                                 "forward_dynamics_gradient_core%s<T,C>(in, out, gravity);" % ("_qdd_minv" if use_qdd_Minv_input else "")])
+        self.gen_add_end_function()
+
+    def gen_forward_dynamics_gradient_kernel(self, use_thread_group=False, use_qdd_Minv_input=False, single_call_timing=False):
+        n = self.spec.n
+        if use_qdd_Minv_input:
+            self._emit_kernel("FD_DU", "forward_dynamics_gradient_kernel", "forward_dynamics_gradient_core_qdd_minv",
+                              "Computes the gradient of forward dynamics", "df_du", ("q_qd", 2 * n, "stride_q_qd"),
+                              [("qdd", n), ("Minv", n * n)], True, "s_q_qd, s_q_qd + %d, nullptr, s_qdd, s_Minv" % n)
+        else:
+            self._emit_kernel("FD_DU", "forward_dynamics_gradient_kernel", "forward_dynamics_gradient_core",
+                              "Computes the gradient of forward dynamics", "df_du", ("q_qd_u", 3 * n, "stride_q_qd_u"),
+                              [], True, "s_q_qd_u, s_q_qd_u + %d, s_q_qd_u + %d, nullptr, nullptr" % (n, 2 * n))
+
+    def gen_forward_dynamics_gradient_host(self, mode=0):
+        def pre(mode):
+            lines = ["const int stride_q_qd = 3*NUM_JOINTS;"]
+            if mode == "full":
+                lines += ["gpuErrchk(hipMemcpyAsync(hd_data->d_q_qd_u,hd_data->h_q_qd_u,stride_q_qd*num_timesteps*sizeof(T),hipMemcpyHostToDevice,streams[0]));",
+                          "if (USE_QDD_MINV_FLAG) {",
+                          "    gpuErrchk(hipMemcpyAsync(hd_data->d_qdd,hd_data->h_qdd,NUM_JOINTS*num_timesteps*sizeof(T),hipMemcpyHostToDevice,streams[1]));",
+                          "    gpuErrchk(hipMemcpyAsync(hd_data->d_Minv,hd_data->h_Minv,NUM_JOINTS*NUM_JOINTS*num_timesteps*sizeof(T),hipMemcpyHostToDevice,streams[2]));",
+                          "}"]
+            return lines
+        launches = [
+            "if (USE_QDD_MINV_FLAG) {forward_dynamics_gradient_kernel<T>@L(hd_data->d_df_du,hd_data->d_q_qd_u,stride_q_qd,hd_data->d_qdd,hd_data->d_Minv,d_robotModel,gravity,num_timesteps);}",
+            "else                   {forward_dynamics_gradient_kernel<T>@L(hd_data->d_df_du,hd_data->d_q_qd_u,stride_q_qd,d_robotModel,gravity,num_timesteps);}"]
+        post = ["// finally transfer the result back",
+                "gpuErrchk(hipMemcpy(hd_data->h_df_du,hd_data->d_df_du,NUM_JOINTS*2*NUM_JOINTS*num_timesteps*sizeof(T),hipMemcpyDeviceToHost));",
+                "gpuErrchk(hipDeviceSynchronize());"]
+        self._emit_host("FD_DU", "forward_dynamics_gradient", "Computes the gradient of forward dynamics",
+                        "template <typename T, bool USE_QDD_MINV_FLAG = false>", True, pre, launches, post, "FD_DU")
+
+    def gen_forward_dynamics_gradient(self, use_thread_group=False):
+        self._emit_core("forward_dynamics_gradient_core",
+                        "Forward-dynamics gradient core (fused): Minv, RNEA(0), qdd, RNEA(qdd), dRNEA, -Minv*dc_du; out = [dqdd/dq | dqdd/dqd]",
+                        cores.core_forward_dynamics_gradient(self.spec, False))
+        self._emit_core("forward_dynamics_gradient_core_qdd_minv",
+                        "Forward-dynamics gradient core with qdd and (upper triangular) Minv supplied",
+                        cores.core_forward_dynamics_gradient(self.spec, True))
+        self.gen_forward_dynamics_gradient_device(use_thread_group, False)
+        self.gen_forward_dynamics_gradient_device(use_thread_group, True)
+        self.gen_forward_dynamics_gradient_kernel(use_thread_group, True)
+        self.gen_forward_dynamics_gradient_kernel(use_thread_group, False)
+        self.gen_forward_dynamics_gradient_host()

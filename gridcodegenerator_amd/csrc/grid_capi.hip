@@ -1,0 +1,308 @@
+// C-ABI shim over the generated header (one shared object per robot).  Declarations + the reference
+// interface each entry point replaces: include/grid_capi.h.  Compile with
+//   hipcc --offload-arch=gfx950 -O3 -fPIC -shared -DGRID_ERRORS_RETURN -DGRID_HEADER='"grid.hip.h"' -DGRID_NS=grid ...
+#define GRID_ERRORS_RETURN 1
+#include GRID_HEADER
+#include <string.h>
+#include <string>
+#include "grid_capi.h"
+
+#ifndef GRID_NS
+#define GRID_NS grid
+#endif
+#ifndef GRID_ROBOT_NAME
+#define GRID_ROBOT_NAME "robot"
+#endif
+namespace G = GRID_NS;
+typedef float T;
+
+struct grid_handle {
+    int device;
+    G::robotModel<T> *d_robotModel;
+    hipStream_t *streams;
+    G::gridData<T> *hd_data;
+    int max_timesteps;
+};
+
+static thread_local std::string g_last_error;
+
+static int grid_fail(const char *what) {
+    hipError_t e = grid_first_error();
+    char buf[512];
+    if (e != hipSuccess) {
+        snprintf(buf, sizeof(buf), "%s: %s (%s:%d)", what, hipGetErrorString(e), grid_first_error_where(), grid_first_error_line());
+        grid_first_error() = hipSuccess;
+        (void)hipGetLastError();
+        g_last_error = buf;
+        return (int)e;
+    }
+    g_last_error = what;
+    return -1;
+}
+static inline int grid_check(const char *what) { return (grid_first_error() == hipSuccess) ? 0 : grid_fail(what); }
+#define GRID_TRY(expr, what) do { hipError_t _e = (expr); if (_e != hipSuccess) { gpuAssert(_e, __FILE__, __LINE__); return grid_fail(what); } } while (0)
+
+static void launch_shape(int K, int blocks, int threads, dim3 *b, dim3 *t) {
+    dim3 ub(blocks > 0 ? blocks : 0, 1, 1), ut(threads > 0 ? threads : 0, 1, 1);
+    if (blocks <= 0 && threads > 0) { ub = dim3((K + threads - 1) / threads > 0 ? (K + threads - 1) / threads : 1, 1, 1); }
+    G::grid_launch_dims(ub, ut, K, b, t);
+}
+
+extern "C" {
+
+const char *grid_robot_name(void) { return GRID_ROBOT_NAME; }
+int grid_num_joints(void) { return G::NUM_JOINTS; }
+int grid_topology_helpers_count(void) { return G::TOPOLOGY_HELPERS_COUNT; }
+const char *grid_compute_dtype(void) { return sizeof(G::grid_compute<float>::type) == 8 ? "f64" : "f32"; }
+const char *grid_last_error(void) { return g_last_error.c_str(); }
+
+int grid_constants(int *out, int count) {
+    const int vals[10] = {G::NUM_JOINTS, G::ID_DYNAMIC_SHARED_MEM_COUNT, G::MINV_DYNAMIC_SHARED_MEM_COUNT, G::FD_DYNAMIC_SHARED_MEM_COUNT,
+                          G::ID_DU_DYNAMIC_SHARED_MEM_COUNT, G::FD_DU_DYNAMIC_SHARED_MEM_COUNT, G::ID_DU_MAX_SHARED_MEM_COUNT,
+                          G::FD_DU_MAX_SHARED_MEM_COUNT, G::SUGGESTED_THREADS, G::SUGGESTED_MAX_BLOCKS};
+    if (out == nullptr || count < 0) { g_last_error = "grid_constants: bad arguments"; return -1; }
+    for (int i = 0; i < count && i < 10; i++) out[i] = vals[i];
+    return 0;
+}
+
+int grid_init(int device, grid_handle **out) {
+    if (out == nullptr) { g_last_error = "grid_init: out is NULL"; return -1; }
+    *out = nullptr;
+    int ndev = 0;
+    GRID_TRY(hipGetDeviceCount(&ndev), "grid_init: hipGetDeviceCount");
+    if (device < 0 || device >= ndev) { g_last_error = "grid_init: no such device"; return -1; }
+    GRID_TRY(hipSetDevice(device), "grid_init: hipSetDevice");
+    grid_handle *h = new grid_handle();
+    h->device = device; h->hd_data = nullptr; h->max_timesteps = 0;
+    h->d_robotModel = G::init_robotModel<T>();
+    h->streams = G::init_grid<T>();
+    if (int rc = grid_check("grid_init")) { delete h; return rc; }
+    *out = h;
+    return 0;
+}
+
+int grid_alloc(grid_handle *h, int max_timesteps) {
+    if (h == nullptr || max_timesteps <= 0) { g_last_error = "grid_alloc: bad arguments"; return -1; }
+    GRID_TRY(hipSetDevice(h->device), "grid_alloc: hipSetDevice");
+    if (h->hd_data != nullptr) {
+        G::close_grid<T>(nullptr, nullptr, h->hd_data);
+        h->hd_data = nullptr; h->max_timesteps = 0;
+    }
+    h->hd_data = G::init_gridData<T>(max_timesteps);
+    if (int rc = grid_check("grid_alloc")) return rc;
+    h->max_timesteps = max_timesteps;
+    return 0;
+}
+
+int grid_close(grid_handle *h) {
+    if (h == nullptr) return 0;
+    (void)hipSetDevice(h->device);
+    G::close_grid<T>(h->streams, h->d_robotModel, h->hd_data);
+    int rc = grid_check("grid_close");
+    delete h;
+    return rc;
+}
+
+int grid_read_model(grid_handle *h, float *h_XImats, int *h_topology) {
+    if (h == nullptr) { g_last_error = "grid_read_model: NULL handle"; return -1; }
+    GRID_TRY(hipSetDevice(h->device), "grid_read_model: hipSetDevice");
+    G::robotModel<T> hm;
+    GRID_TRY(hipMemcpy(&hm, h->d_robotModel, sizeof(hm), hipMemcpyDeviceToHost), "grid_read_model: struct");
+    if (h_XImats) GRID_TRY(hipMemcpy(h_XImats, hm.d_XImats, G::XIMATS_MODEL_COUNT * sizeof(T), hipMemcpyDeviceToHost), "grid_read_model: XImats");
+    if (h_topology && G::TOPOLOGY_HELPERS_COUNT > 0)
+        GRID_TRY(hipMemcpy(h_topology, hm.d_topology_helpers, G::TOPOLOGY_HELPERS_COUNT * sizeof(int), hipMemcpyDeviceToHost), "grid_read_model: topology");
+    return 0;
+}
+
+static int host_prep(grid_handle *h, const float *h_q_qd_u, int K, const char *who) {
+    if (h == nullptr || h_q_qd_u == nullptr || K <= 0) { g_last_error = std::string(who) + ": bad arguments"; return -1; }
+    if (h->hd_data == nullptr || K > h->max_timesteps) { g_last_error = std::string(who) + ": call grid_alloc(h, >= num_timesteps) first"; return -1; }
+    hipError_t e = hipSetDevice(h->device);
+    if (e != hipSuccess) { gpuAssert(e, __FILE__, __LINE__); return grid_fail(who); }
+    memcpy(h->hd_data->h_q_qd_u, h_q_qd_u, sizeof(T) * 3 * G::NUM_JOINTS * (size_t)K);
+    return 0;
+}
+
+int grid_inverse_dynamics(grid_handle *h, const float *h_q_qd_u, const float *h_qdd, float *h_c, int K, float gravity) {
+    if (int rc = host_prep(h, h_q_qd_u, K, "grid_inverse_dynamics")) return rc;
+    if (h_c == nullptr) { g_last_error = "grid_inverse_dynamics: h_c is NULL"; return -1; }
+    const dim3 z(0, 0, 0);
+    if (h_qdd) { memcpy(h->hd_data->h_qdd, h_qdd, sizeof(T) * G::NUM_JOINTS * (size_t)K);
+                 G::inverse_dynamics<T, true, false>(h->hd_data, h->d_robotModel, gravity, K, z, z, h->streams); }
+    else       { G::inverse_dynamics<T, false, false>(h->hd_data, h->d_robotModel, gravity, K, z, z, h->streams); }
+    if (int rc = grid_check("grid_inverse_dynamics")) return rc;
+    memcpy(h_c, h->hd_data->h_c, sizeof(T) * G::NUM_JOINTS * (size_t)K);
+    return 0;
+}
+
+int grid_direct_minv(grid_handle *h, const float *h_q_qd_u, float *h_Minv, int K) {
+    if (int rc = host_prep(h, h_q_qd_u, K, "grid_direct_minv")) return rc;
+    if (h_Minv == nullptr) { g_last_error = "grid_direct_minv: h_Minv is NULL"; return -1; }
+    const dim3 z(0, 0, 0);
+    G::direct_minv<T, false>(h->hd_data, h->d_robotModel, K, z, z, h->streams);
+    if (int rc = grid_check("grid_direct_minv")) return rc;
+    memcpy(h_Minv, h->hd_data->h_Minv, sizeof(T) * G::NUM_JOINTS * G::NUM_JOINTS * (size_t)K);
+    return 0;
+}
+
+int grid_forward_dynamics(grid_handle *h, const float *h_q_qd_u, float *h_qdd, int K, float gravity) {
+    if (int rc = host_prep(h, h_q_qd_u, K, "grid_forward_dynamics")) return rc;
+    if (h_qdd == nullptr) { g_last_error = "grid_forward_dynamics: h_qdd is NULL"; return -1; }
+    const dim3 z(0, 0, 0);
+    G::forward_dynamics<T>(h->hd_data, h->d_robotModel, gravity, K, z, z, h->streams);
+    if (int rc = grid_check("grid_forward_dynamics")) return rc;
+    memcpy(h_qdd, h->hd_data->h_qdd, sizeof(T) * G::NUM_JOINTS * (size_t)K);
+    return 0;
+}
+
+int grid_inverse_dynamics_gradient(grid_handle *h, const float *h_q_qd_u, const float *h_qdd, float *h_dc_du, int K, float gravity) {
+    if (int rc = host_prep(h, h_q_qd_u, K, "grid_inverse_dynamics_gradient")) return rc;
+    if (h_dc_du == nullptr) { g_last_error = "grid_inverse_dynamics_gradient: h_dc_du is NULL"; return -1; }
+    const dim3 z(0, 0, 0);
+    if (h_qdd) { memcpy(h->hd_data->h_qdd, h_qdd, sizeof(T) * G::NUM_JOINTS * (size_t)K);
+                 G::inverse_dynamics_gradient<T, true, false>(h->hd_data, h->d_robotModel, gravity, K, z, z, h->streams); }
+    else       { G::inverse_dynamics_gradient<T, false, false>(h->hd_data, h->d_robotModel, gravity, K, z, z, h->streams); }
+    if (int rc = grid_check("grid_inverse_dynamics_gradient")) return rc;
+    memcpy(h_dc_du, h->hd_data->h_dc_du, sizeof(T) * 2 * G::NUM_JOINTS * G::NUM_JOINTS * (size_t)K);
+    return 0;
+}
+
+int grid_forward_dynamics_gradient(grid_handle *h, const float *h_q_qd_u, const float *h_qdd, const float *h_Minv, float *h_df_du,
+                                   int K, float gravity) {
+    if (int rc = host_prep(h, h_q_qd_u, K, "grid_forward_dynamics_gradient")) return rc;
+    if (h_df_du == nullptr) { g_last_error = "grid_forward_dynamics_gradient: h_df_du is NULL"; return -1; }
+    if ((h_qdd == nullptr) != (h_Minv == nullptr)) { g_last_error = "grid_forward_dynamics_gradient: pass both h_qdd and h_Minv or neither"; return -1; }
+    const dim3 z(0, 0, 0);
+    if (h_qdd) {
+        memcpy(h->hd_data->h_qdd, h_qdd, sizeof(T) * G::NUM_JOINTS * (size_t)K);
+        memcpy(h->hd_data->h_Minv, h_Minv, sizeof(T) * G::NUM_JOINTS * G::NUM_JOINTS * (size_t)K);
+        G::forward_dynamics_gradient<T, true>(h->hd_data, h->d_robotModel, gravity, K, z, z, h->streams);
+    } else {
+        G::forward_dynamics_gradient<T, false>(h->hd_data, h->d_robotModel, gravity, K, z, z, h->streams);
+    }
+    if (int rc = grid_check("grid_forward_dynamics_gradient")) return rc;
+    memcpy(h_df_du, h->hd_data->h_df_du, sizeof(T) * 2 * G::NUM_JOINTS * G::NUM_JOINTS * (size_t)K);
+    return 0;
+}
+
+// ---- device-pointer launches ------------------------------------------------------------------
+static int launch_alg(grid_handle *h, int alg, float *d_out, const float *d_in, int stride, const float *d_qdd, const float *d_Minv,
+                      int K, float gravity, int blocks, int threads, hipStream_t s) {
+    dim3 b, t;
+    launch_shape(K, blocks, threads, &b, &t);
+    switch (alg) {
+    case GRID_ALG_ID: {
+        const size_t lds = G::grid_lds_bytes<T>(t, G::ID_DYNAMIC_SHARED_MEM_COUNT / (G::SUGGESTED_THREADS / G::GRID_WAVE_SIZE));
+        if (d_qdd) G::inverse_dynamics_kernel<T><<<b, t, lds, s>>>(d_out, d_in, stride, d_qdd, h->d_robotModel, gravity, K);
+        else       G::inverse_dynamics_kernel<T><<<b, t, lds, s>>>(d_out, d_in, stride, h->d_robotModel, gravity, K);
+        break; }
+    case GRID_ALG_MINV: {
+        const size_t lds = G::grid_lds_bytes<T>(t, G::MINV_DYNAMIC_SHARED_MEM_COUNT / (G::SUGGESTED_THREADS / G::GRID_WAVE_SIZE));
+        G::direct_minv_kernel<T><<<b, t, lds, s>>>(d_out, d_in, stride, h->d_robotModel, K);
+        break; }
+    case GRID_ALG_FD: {
+        const size_t lds = G::grid_lds_bytes<T>(t, G::FD_DYNAMIC_SHARED_MEM_COUNT / (G::SUGGESTED_THREADS / G::GRID_WAVE_SIZE));
+        G::forward_dynamics_kernel<T><<<b, t, lds, s>>>(d_out, d_in, stride, h->d_robotModel, gravity, K);
+        break; }
+    case GRID_ALG_ID_DU: {
+        const size_t lds = G::grid_lds_bytes<T>(t, G::ID_DU_DYNAMIC_SHARED_MEM_COUNT / (G::SUGGESTED_THREADS / G::GRID_WAVE_SIZE));
+        if (d_qdd) G::inverse_dynamics_gradient_kernel<T><<<b, t, lds, s>>>(d_out, d_in, stride, d_qdd, h->d_robotModel, gravity, K);
+        else       G::inverse_dynamics_gradient_kernel<T><<<b, t, lds, s>>>(d_out, d_in, stride, h->d_robotModel, gravity, K);
+        break; }
+    case GRID_ALG_FD_DU: {
+        const size_t lds = G::grid_lds_bytes<T>(t, G::FD_DU_DYNAMIC_SHARED_MEM_COUNT / (G::SUGGESTED_THREADS / G::GRID_WAVE_SIZE));
+        if (d_qdd && d_Minv) G::forward_dynamics_gradient_kernel<T><<<b, t, lds, s>>>(d_out, d_in, stride, d_qdd, d_Minv, h->d_robotModel, gravity, K);
+        else                 G::forward_dynamics_gradient_kernel<T><<<b, t, lds, s>>>(d_out, d_in, stride, h->d_robotModel, gravity, K);
+        break; }
+    default:
+        g_last_error = "unknown algorithm id"; return -1;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { gpuAssert(e, __FILE__, __LINE__); return grid_fail("kernel launch"); }
+    return 0;
+}
+
+static int dev_prep(grid_handle *h, const void *d_out, const void *d_in, int K, const char *who) {
+    if (h == nullptr || d_out == nullptr || d_in == nullptr || K <= 0) { g_last_error = std::string(who) + ": bad arguments"; return -1; }
+    hipError_t e = hipSetDevice(h->device);
+    if (e != hipSuccess) { gpuAssert(e, __FILE__, __LINE__); return grid_fail(who); }
+    return 0;
+}
+static inline hipStream_t pick_stream(grid_handle *h, void *stream) { return stream ? (hipStream_t)stream : h->streams[0]; }
+
+int grid_inverse_dynamics_device(grid_handle *h, float *d_c, const float *d_q_qd, int stride_q_qd, const float *d_qdd,
+                                 int K, float gravity, int blocks, int threads, void *stream) {
+    if (int rc = dev_prep(h, d_c, d_q_qd, K, "grid_inverse_dynamics_device")) return rc;
+    return launch_alg(h, GRID_ALG_ID, d_c, d_q_qd, stride_q_qd, d_qdd, nullptr, K, gravity, blocks, threads, pick_stream(h, stream));
+}
+int grid_direct_minv_device(grid_handle *h, float *d_Minv, const float *d_q, int stride_q, int K, int blocks, int threads, void *stream) {
+    if (int rc = dev_prep(h, d_Minv, d_q, K, "grid_direct_minv_device")) return rc;
+    return launch_alg(h, GRID_ALG_MINV, d_Minv, d_q, stride_q, nullptr, nullptr, K, 0.0f, blocks, threads, pick_stream(h, stream));
+}
+int grid_forward_dynamics_device(grid_handle *h, float *d_qdd, const float *d_q_qd_u, int stride_q_qd_u,
+                                 int K, float gravity, int blocks, int threads, void *stream) {
+    if (int rc = dev_prep(h, d_qdd, d_q_qd_u, K, "grid_forward_dynamics_device")) return rc;
+    return launch_alg(h, GRID_ALG_FD, d_qdd, d_q_qd_u, stride_q_qd_u, nullptr, nullptr, K, gravity, blocks, threads, pick_stream(h, stream));
+}
+int grid_inverse_dynamics_gradient_device(grid_handle *h, float *d_dc_du, const float *d_q_qd, int stride_q_qd, const float *d_qdd,
+                                          int K, float gravity, int blocks, int threads, void *stream) {
+    if (int rc = dev_prep(h, d_dc_du, d_q_qd, K, "grid_inverse_dynamics_gradient_device")) return rc;
+    return launch_alg(h, GRID_ALG_ID_DU, d_dc_du, d_q_qd, stride_q_qd, d_qdd, nullptr, K, gravity, blocks, threads, pick_stream(h, stream));
+}
+int grid_forward_dynamics_gradient_device(grid_handle *h, float *d_df_du, const float *d_q_qd_u, int stride_q_qd_u,
+                                          const float *d_qdd, const float *d_Minv, int K, float gravity, int blocks, int threads, void *stream) {
+    if (int rc = dev_prep(h, d_df_du, d_q_qd_u, K, "grid_forward_dynamics_gradient_device")) return rc;
+    if ((d_qdd == nullptr) != (d_Minv == nullptr)) { g_last_error = "grid_forward_dynamics_gradient_device: pass both d_qdd and d_Minv or neither"; return -1; }
+    return launch_alg(h, GRID_ALG_FD_DU, d_df_du, d_q_qd_u, stride_q_qd_u, d_qdd, d_Minv, K, gravity, blocks, threads, pick_stream(h, stream));
+}
+
+int grid_synchronize(grid_handle *h, void *stream) {
+    if (h == nullptr) { g_last_error = "grid_synchronize: NULL handle"; return -1; }
+    GRID_TRY(hipSetDevice(h->device), "grid_synchronize: hipSetDevice");
+    GRID_TRY(hipStreamSynchronize(pick_stream(h, stream)), "grid_synchronize");
+    return 0;
+}
+
+int grid_time_device(grid_handle *h, int alg, float *d_out, const float *d_in, int stride, const float *d_qdd, const float *d_Minv,
+                     int K, float gravity, int blocks, int threads, void *stream, int reps, float *ms_per_launch) {
+    if (int rc = dev_prep(h, d_out, d_in, K, "grid_time_device")) return rc;
+    if (reps <= 0 || ms_per_launch == nullptr) { g_last_error = "grid_time_device: bad arguments"; return -1; }
+    hipStream_t s = pick_stream(h, stream);
+    hipEvent_t e0, e1;
+    GRID_TRY(hipEventCreate(&e0), "grid_time_device: event");
+    GRID_TRY(hipEventCreate(&e1), "grid_time_device: event");
+    GRID_TRY(hipEventRecord(e0, s), "grid_time_device: record");
+    for (int r = 0; r < reps; r++) {
+        if (int rc = launch_alg(h, alg, d_out, d_in, stride, d_qdd, d_Minv, K, gravity, blocks, threads, s)) return rc;
+    }
+    GRID_TRY(hipEventRecord(e1, s), "grid_time_device: record");
+    GRID_TRY(hipEventSynchronize(e1), "grid_time_device: sync");
+    float ms = 0.f;
+    GRID_TRY(hipEventElapsedTime(&ms, e0, e1), "grid_time_device: elapsed");
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *ms_per_launch = ms / reps;
+    return 0;
+}
+
+int grid_kernel_attributes(int alg, int variant, int *out) {
+    if (out == nullptr) { g_last_error = "grid_kernel_attributes: out is NULL"; return -1; }
+    const void *fn = nullptr;
+    typedef void (*k6)(T *, const T *, const int, const G::robotModel<T> *, const T, const int);
+    typedef void (*k7)(T *, const T *, const int, const T *, const G::robotModel<T> *, const T, const int);
+    typedef void (*k8)(T *, const T *, const int, const T *, const T *, const G::robotModel<T> *, const T, const int);
+    typedef void (*k5)(T *, const T *, const int, const G::robotModel<T> *, const int);
+    switch (alg) {
+    case GRID_ALG_ID:    fn = variant ? (const void *)static_cast<k7>(&G::inverse_dynamics_kernel<T>) : (const void *)static_cast<k6>(&G::inverse_dynamics_kernel<T>); break;
+    case GRID_ALG_MINV:  fn = (const void *)static_cast<k5>(&G::direct_minv_kernel<T>); break;
+    case GRID_ALG_FD:    fn = (const void *)static_cast<k6>(&G::forward_dynamics_kernel<T>); break;
+    case GRID_ALG_ID_DU: fn = variant ? (const void *)static_cast<k7>(&G::inverse_dynamics_gradient_kernel<T>) : (const void *)static_cast<k6>(&G::inverse_dynamics_gradient_kernel<T>); break;
+    case GRID_ALG_FD_DU: fn = variant ? (const void *)static_cast<k8>(&G::forward_dynamics_gradient_kernel<T>) : (const void *)static_cast<k6>(&G::forward_dynamics_gradient_kernel<T>); break;
+    default: g_last_error = "unknown algorithm id"; return -1;
+    }
+    hipFuncAttributes a;
+    GRID_TRY(hipFuncGetAttributes(&a, fn), "grid_kernel_attributes");
+    out[0] = a.numRegs; out[1] = (int)a.sharedSizeBytes; out[2] = (int)a.localSizeBytes; out[3] = a.maxThreadsPerBlock;
+    return 0;
+}
+
+}  // extern "C"

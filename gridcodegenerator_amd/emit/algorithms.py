@@ -1,0 +1,326 @@
+"""Rigid-body-dynamics algorithms written against the tracer (trace.py).
+
+Each function runs the algorithm ONCE at generation time on traced scalars for one configuration --
+the emitted code is what a single wavefront lane executes.  The mathematics is the reference's:
+
+    RNEA                 algorithms/_inverse_dynamics.py:33-304     (oracle: _test.py:5-115)
+    direct Minv          algorithms/_direct_minv.py:23-382          (oracle: _test.py:117-226)
+    FD finish            algorithms/_forward_dynamics.py:21-49
+    RNEA gradient        algorithms/_inverse_dynamics_gradient.py:27-650  (oracle: _test.py:229-488)
+    FD gradient          algorithms/_forward_dynamics_gradient.py:7-57    (oracle: _test.py:496-520)
+
+but the *schedule* is not: there are no BFS levels, barriers, thread-strided loops or atomics (one
+lane owns the whole configuration, so joints are simply visited in id order: parent < child), the
+reference's sparsity-compressed column storage (section 8(a) a8/a12 of SURVEY.md) is replaced by
+dictionaries keyed (joint, column) that only ever hold the structurally non-zero columns, and every
+6x6 product is specialised entry-by-entry by the tracer.
+"""
+from .trace import V
+
+_I3 = range(3)
+
+
+# ------------------------------------------------------------------------------------------------
+# spatial algebra on lists of traced scalars
+# ------------------------------------------------------------------------------------------------
+def zeros6(tr):
+    return [tr.zero() for _ in range(6)]
+
+
+def vadd(a, b):
+    return [x + y for x, y in zip(a, b)]
+
+
+def vsub(a, b):
+    return [x - y for x, y in zip(a, b)]
+
+
+def matvec(tr, M, v):
+    return [tr.dot([(M[r][c], v[c]) for c in range(6)]) for r in range(6)]
+
+
+def matvec_acc(tr, M, v, acc):
+    return [tr.dot([(M[r][c], v[c]) for c in range(6)], init=acc[r]) for r in range(6)]
+
+
+def mattvec(tr, M, v):
+    return [tr.dot([(M[r][c], v[r]) for r in range(6)]) for c in range(6)]
+
+
+def mattvec_acc(tr, M, v, acc):
+    return [tr.dot([(M[r][c], v[r]) for r in range(6)], init=acc[c]) for c in range(6)]
+
+
+def mxS(tr, s, vec, alpha=None):
+    """crm(vec) e_s * alpha  (reference helpers/_spatial_algebra_helpers.py:62-147 mxK family)."""
+    z = tr.zero()
+    v = vec
+    table = {
+        0: [z, v[2], -v[1], z, v[5], -v[4]],
+        1: [-v[2], z, v[0], -v[5], z, v[3]],
+        2: [v[1], -v[0], z, v[4], -v[3], z],
+        3: [z, z, z, z, v[2], -v[1]],
+        4: [z, z, z, -v[2], z, v[0]],
+        5: [z, z, z, v[1], -v[0], z],
+    }[s]
+    if alpha is None:
+        return table
+    return [x * alpha for x in table]
+
+
+def fxv(tr, a, b):
+    """crf(a) b  (reference helpers/_spatial_algebra_helpers.py:234-257 fx_times_v)."""
+    d = tr.dot
+    return [
+        d([(-a[2], b[1]), (a[1], b[2]), (-a[5], b[4]), (a[4], b[5])]),
+        d([(a[2], b[0]), (-a[0], b[2]), (a[5], b[3]), (-a[3], b[5])]),
+        d([(-a[1], b[0]), (a[0], b[1]), (-a[4], b[3]), (a[3], b[4])]),
+        d([(-a[2], b[4]), (a[1], b[5])]),
+        d([(a[2], b[3]), (-a[0], b[5])]),
+        d([(-a[1], b[3]), (a[0], b[4])]),
+    ]
+
+
+def fxS(tr, s, f):
+    """crf(e_s) f -- force cross product with the joint axis (see oracle docstring: prismatic fix)."""
+    S = [tr.const(1.0 if i == s else 0.0) for i in range(6)]
+    return fxv(tr, S, f)
+
+
+# ------------------------------------------------------------------------------------------------
+# model quantities
+# ------------------------------------------------------------------------------------------------
+def build_X(tr, spec, q, trig):
+    """X_j(q_j) entries as traced scalars.  trig[j] = (sin q_j, cos q_j) or None for joints without trig."""
+    X = []
+    for j in range(spec.n):
+        A, B, D, C = spec.Xbasis[j]
+        s, c = trig[j] if trig[j] is not None else (tr.zero(), tr.zero())
+        Xj = [[None] * 6 for _ in range(6)]
+        for r in range(6):
+            for col in range(6):
+                if r < 3 and col >= 3:
+                    Xj[r][col] = tr.zero()
+                    continue
+                if r >= 3 and col >= 3:  # bottom-right == top-left
+                    Xj[r][col] = Xj[r - 3][col - 3]
+                    continue
+                Xj[r][col] = tr.dot([(float(A[r, col]), s), (float(B[r, col]), c), (float(D[r, col]), q[j])],
+                                    init=tr.const(float(C[r, col])))
+        X.append(Xj)
+    return X
+
+
+def build_I(tr, spec):
+    return [[[tr.const(float(spec.Imats[j][r, c])) for c in range(6)] for r in range(6)] for j in range(spec.n)]
+
+
+def trig_from_q(tr, spec, q):
+    return [(tr.sin(q[j]), tr.cos(q[j])) if spec.uses_trig[j] else None for j in range(spec.n)]
+
+
+# ------------------------------------------------------------------------------------------------
+# RNEA
+# ------------------------------------------------------------------------------------------------
+def rnea(tr, spec, X, I, qd, qdd, gravity):
+    """Returns c (n), v, a, f (n x 6; f accumulated over subtrees as in the reference's s_vaf)."""
+    n = spec.n
+    v = [None] * n; a = [None] * n; f = [None] * n
+    for j in range(n):
+        p, s = spec.parent[j], spec.S_ind[j]
+        if p == -1:
+            vj = zeros6(tr)
+            vj[s] = qd[j]
+            aj = [X[j][r][5] * gravity for r in range(6)]
+        else:
+            vj = matvec(tr, X[j], v[p])
+            vj[s] = vj[s] + qd[j]
+            aj = matvec(tr, X[j], a[p])
+            aj = vadd(aj, mxS(tr, s, vj, qd[j]))
+        if qdd is not None:
+            aj[s] = aj[s] + qdd[j]
+        v[j], a[j] = vj, aj
+        Iv = matvec(tr, I[j], vj)
+        f[j] = vadd(matvec(tr, I[j], aj), fxv(tr, vj, Iv))
+    c = [None] * n
+    for j in range(n - 1, -1, -1):
+        p, s = spec.parent[j], spec.S_ind[j]
+        c[j] = f[j][s] + qd[j] * spec.damping[j]
+        if p != -1:
+            f[p] = mattvec_acc(tr, X[j], f[j], f[p])
+    return c, v, a, f
+
+
+# ------------------------------------------------------------------------------------------------
+# direct Minv
+# ------------------------------------------------------------------------------------------------
+def direct_minv(tr, spec, X, I):
+    """Upper-triangular Minv[j][k] (k >= j) as traced scalars; entries k < j are None."""
+    n = spec.n
+    IA = [[[I[j][r][c] if r <= c else None for c in range(6)] for r in range(6)] for j in range(n)]
+    for j in range(n):  # mirror so IA[r][c] is IA[c][r] (symmetric by construction)
+        for r in range(6):
+            for c in range(r):
+                IA[j][r][c] = IA[j][c][r]
+    Minv = [[None] * n for _ in range(n)]
+    F = {}       # backward-pass F[(j, k)] -> 6-vector
+    U = [None] * n
+    Dinv = [None] * n
+    for j in range(n - 1, -1, -1):
+        p, s = spec.parent[j], spec.S_ind[j]
+        Uj = [IA[j][r][s] for r in range(6)]
+        Dj = tr.rcp(Uj[s])
+        U[j], Dinv[j] = Uj, Dj
+        Minv[j][j] = Dj
+        for k in spec.subtree[j]:
+            if k != j:
+                Fjk = F.get((j, k))
+                Minv[j][k] = -(Dj * Fjk[s]) if Fjk is not None else tr.zero()
+        if p == -1:
+            continue
+        for k in spec.subtree[j]:
+            Fjk = F.get((j, k), None)
+            upd = [Uj[r] * Minv[j][k] for r in range(6)]
+            Fjk = upd if Fjk is None else vadd(Fjk, upd)
+            F[(j, k)] = Fjk
+            F[(p, k)] = mattvec_acc(tr, X[j], Fjk, F.get((p, k), zeros6(tr)))
+        # articulated inertia: Ia = IA - U Dinv U^T (row/col s vanish identically), IA_p += X^T Ia X
+        UD = [Uj[r] * Dj for r in range(6)]
+        Ia = [[None] * 6 for _ in range(6)]
+        for r in range(6):
+            for c in range(r, 6):
+                if r == s or c == s:
+                    val = tr.zero()
+                else:
+                    val = tr.fma(-UD[r], Uj[c], IA[j][r][c])
+                Ia[r][c] = val
+                Ia[c][r] = val
+        Tm = [[tr.dot([(Ia[r][k], X[j][k][c]) for k in range(6)]) for c in range(6)] for r in range(6)]
+        for r in range(6):
+            for c in range(r, 6):
+                val = tr.dot([(X[j][k][r], Tm[k][c]) for k in range(6)], init=IA[p][r][c])
+                IA[p][r][c] = val
+                IA[p][c][r] = val
+    Fn = {}      # forward-pass F (the reference overwrites F in place, _test.py:198-200)
+    for j in range(n):
+        p, s = spec.parent[j], spec.S_ind[j]
+        if p != -1:
+            UX = mattvec(tr, X[j], U[j])
+            for k in range(j, n):
+                Fpk = Fn.get((p, k))
+                if Fpk is None:
+                    continue
+                corr = Dinv[j] * tr.dot([(UX[r], Fpk[r]) for r in range(6)])
+                Minv[j][k] = (Minv[j][k] if Minv[j][k] is not None else tr.zero()) - corr
+        if not spec.children[j]:
+            for k in range(j, n):
+                if Minv[j][k] is None:
+                    Minv[j][k] = tr.zero()
+            continue
+        for k in range(j, n):
+            if Minv[j][k] is None:
+                Minv[j][k] = tr.zero()
+            Fjk = zeros6(tr)
+            Fjk[s] = Minv[j][k]
+            if p != -1 and (p, k) in Fn:
+                Fjk = matvec_acc(tr, X[j], Fn[(p, k)], Fjk)
+            if all(x.is_zero() for x in Fjk):
+                continue
+            Fn[(j, k)] = Fjk
+    return Minv
+
+
+def minv_sym(Minv, r, c):
+    return Minv[r][c] if r <= c else Minv[c][r]
+
+
+def fd_finish(tr, spec, Minv, u, c):
+    """qdd = Minv_sym (u - c)  (algorithms/_forward_dynamics.py:21-49)."""
+    n = spec.n
+    umc = [u[k] - c[k] for k in range(n)]
+    return [tr.dot([(minv_sym(Minv, r, k), umc[k]) for k in range(n)]) for r in range(n)]
+
+
+# ------------------------------------------------------------------------------------------------
+# gradient of RNEA
+# ------------------------------------------------------------------------------------------------
+def rnea_grad(tr, spec, X, I, qd, v, a, f, gravity):
+    """dc_dq[j][col], dc_dqd[j][col] (traced scalars; structurally-zero entries are const 0).
+
+    v, a, f as returned by rnea() (f accumulated).  Follows _test.py:229-488 column by column;
+    only the columns (ancestors + self, then + subtree on the way back) that can be non-zero exist.
+    """
+    n = spec.n
+    zero6 = zeros6(tr)
+    dv = {}; da = {}; df = {}       # (j, col) -> (dq 6-vector, dqd 6-vector)
+    for j in range(n):
+        p, s = spec.parent[j], spec.S_ind[j]
+        if p != -1:
+            Xv = matvec(tr, X[j], v[p])
+            Xa = matvec(tr, X[j], a[p])
+        else:
+            Xv = None
+            Xa = [X[j][r][5] * gravity for r in range(6)]
+        Iv = matvec(tr, I[j], v[j])
+        cols = spec.ancestors[j] + [j]
+        for col in cols:
+            if col != j:
+                dvq = matvec(tr, X[j], dv[(p, col)][0])
+                dvqd = matvec(tr, X[j], dv[(p, col)][1])
+            else:
+                dvq = mxS(tr, s, Xv) if Xv is not None else list(zero6)
+                dvqd = list(zero6)
+                dvqd[s] = tr.const(1.0)
+            dv[(j, col)] = (dvq, dvqd)
+            daq = mxS(tr, s, dvq, qd[j])
+            daqd = mxS(tr, s, dvqd, qd[j])
+            if col == j:
+                daq = vadd(daq, mxS(tr, s, Xa))
+                daqd = vadd(daqd, mxS(tr, s, v[j]))
+            elif p != -1:
+                daq = matvec_acc(tr, X[j], da[(p, col)][0], daq)
+                daqd = matvec_acc(tr, X[j], da[(p, col)][1], daqd)
+            da[(j, col)] = (daq, daqd)
+            out = []
+            for (dvx, dax) in ((dvq, daq), (dvqd, daqd)):
+                # df = I da + crf(v) (I dv) + crf(dv) (I v)
+                Idv = matvec(tr, I[j], dvx)
+                t = matvec(tr, I[j], dax)
+                t = vadd(t, fxv(tr, v[j], Idv))
+                t = vadd(t, fxv(tr, dvx, Iv))
+                out.append(t)
+            df[(j, col)] = tuple(out)
+    # backward pass: df_parent[col] += X^T df_j[col] (+ X^T crf(S) f_j on the self column of dq)
+    for j in range(n - 1, 0, -1):
+        p, s = spec.parent[j], spec.S_ind[j]
+        if p == -1:
+            continue
+        seed = fxS(tr, s, f[j])
+        for col in spec.ancestors[j] + spec.subtree[j]:
+            dq_j, dqd_j = df[(j, col)]
+            if col == j:
+                dq_j = vadd(dq_j, seed)
+            prev = df.get((p, col), (zero6, zero6))
+            df[(p, col)] = (mattvec_acc(tr, X[j], dq_j, prev[0]), mattvec_acc(tr, X[j], dqd_j, prev[1]))
+    dc_dq = [[tr.zero() for _ in range(n)] for _ in range(n)]
+    dc_dqd = [[tr.zero() for _ in range(n)] for _ in range(n)]
+    for j in range(n):
+        s = spec.S_ind[j]
+        for col in spec.ancestors[j] + spec.subtree[j]:
+            dc_dq[j][col] = df[(j, col)][0][s]
+            dc_dqd[j][col] = df[(j, col)][1][s]
+            if col == j and spec.damping[j] != 0.0:
+                dc_dqd[j][col] = dc_dqd[j][col] + spec.damping[j]
+    return dc_dq, dc_dqd
+
+
+def fd_grad_finish(tr, spec, Minv, dc_dq, dc_dqd):
+    """df_du = -Minv_sym [dc_dq | dc_dqd]  (algorithms/_forward_dynamics_gradient.py:48-57)."""
+    n = spec.n
+    out_q = [[None] * n for _ in range(n)]
+    out_qd = [[None] * n for _ in range(n)]
+    for col in range(n):
+        for r in range(n):
+            out_q[r][col] = -tr.dot([(minv_sym(Minv, r, k), dc_dq[k][col]) for k in range(n)])
+            out_qd[r][col] = -tr.dot([(minv_sym(Minv, r, k), dc_dqd[k][col]) for k in range(n)])
+    return out_q, out_qd

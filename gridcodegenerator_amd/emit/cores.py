@@ -1,0 +1,191 @@
+"""Build the traces ("cores") for each public algorithm variant.
+
+A core is one straight-line function ``name<T, C>(in, out, gravity)`` over an input accessor
+(``in.q(j)``, ``in.qd(j)``, ``in.u(j)``, ``in.qdd(j)``, ``in.Minv(i)``) and an output sink
+(``out.put(i, value)``); kernels plug LDS-staged accessors in, the pointer-style ``_device`` API and
+the host test harness plug plain-pointer accessors in.
+
+Output index conventions (the reference's buffer layouts):
+    c, qdd            i = joint
+    Minv              i = n*col + row, column-major, upper triangle, lower half written as 0
+    dc_du / df_du     i = n*col + row for d/dq (col < n), n*n + n*col + row for d/dqd
+"""
+from . import algorithms as alg
+from .trace import Tracer
+
+
+def _inputs(tr, spec, names, style):
+    n = spec.n
+    if style == "core":
+        return {nm: [tr.inp("in.%s(%d)" % (nm, j)) for j in range(n)] for nm in names}
+    return {nm: [tr.inp("s_%s[%d]" % (nm, j)) for j in range(n)] for nm in names}
+
+
+def _setup(spec, names, style="core"):
+    """style "core": accessor inputs, sin/cos traced from q.  style "inner": the reference's pointer
+    API (s_q, s_qd, ...) with sin/cos read from the per-lane s_XImats = [sin q | cos q] table that
+    load_update_XImats_helpers fills (the lane-private analogue of helpers/_topology_helpers.py:90-182)."""
+    tr = Tracer()
+    ins = _inputs(tr, spec, names, style)
+    g = tr.inp("gravity")
+    if style == "core":
+        trig = alg.trig_from_q(tr, spec, ins["q"])
+    else:
+        trig = [(tr.inp("s_XImats[%d]" % j), tr.inp("s_XImats[%d]" % (spec.n + j))) if spec.uses_trig[j] else None
+                for j in range(spec.n)]
+    X = alg.build_X(tr, spec, ins["q"], trig)
+    I = alg.build_I(tr, spec)
+    return tr, ins, g, X, I
+
+
+def core_inverse_dynamics(spec, use_qdd):
+    tr, ins, g, X, I = _setup(spec, ["q", "qd"] + (["qdd"] if use_qdd else []))
+    c, v, a, f = alg.rnea(tr, spec, X, I, ins["qd"], ins.get("qdd"), g)
+    for j in range(spec.n):
+        tr.out(j, c[j])
+    return tr
+
+
+def core_inverse_dynamics_vaf(spec, use_qdd):
+    tr, ins, g, X, I = _setup(spec, ["q", "qd"] + (["qdd"] if use_qdd else []))
+    c, v, a, f = alg.rnea(tr, spec, X, I, ins["qd"], ins.get("qdd"), g)
+    n = spec.n
+    for j in range(n):
+        for r in range(6):
+            tr.out(6 * j + r, v[j][r])
+    for j in range(n):
+        for r in range(6):
+            tr.out(6 * n + 6 * j + r, a[j][r])
+    for j in range(n):
+        for r in range(6):
+            tr.out(12 * n + 6 * j + r, f[j][r])
+    return tr
+
+
+def _out_minv(tr, spec, Minv):
+    n = spec.n
+    for col in range(n):
+        for row in range(n):
+            tr.out(n * col + row, Minv[row][col] if row <= col else tr.zero())
+
+
+def core_direct_minv(spec):
+    tr, ins, g, X, I = _setup(spec, ["q"])
+    Minv = alg.direct_minv(tr, spec, X, I)
+    _out_minv(tr, spec, Minv)
+    return tr
+
+
+def core_forward_dynamics(spec):
+    tr, ins, g, X, I = _setup(spec, ["q", "qd", "u"])
+    Minv = alg.direct_minv(tr, spec, X, I)
+    c, v, a, f = alg.rnea(tr, spec, X, I, ins["qd"], None, g)
+    qdd = alg.fd_finish(tr, spec, Minv, ins["u"], c)
+    for j in range(spec.n):
+        tr.out(j, qdd[j])
+    return tr
+
+
+def _out_grad(tr, spec, dq, dqd):
+    n = spec.n
+    for col in range(n):
+        for row in range(n):
+            tr.out(n * col + row, dq[row][col])
+    for col in range(n):
+        for row in range(n):
+            tr.out(n * n + n * col + row, dqd[row][col])
+
+
+def core_inverse_dynamics_gradient(spec, use_qdd):
+    tr, ins, g, X, I = _setup(spec, ["q", "qd"] + (["qdd"] if use_qdd else []))
+    c, v, a, f = alg.rnea(tr, spec, X, I, ins["qd"], ins.get("qdd"), g)
+    dq, dqd = alg.rnea_grad(tr, spec, X, I, ins["qd"], v, a, f, g)
+    _out_grad(tr, spec, dq, dqd)
+    return tr
+
+
+def core_forward_dynamics_gradient(spec, use_qdd_minv):
+    n = spec.n
+    if use_qdd_minv:
+        tr, ins, g, X, I = _setup(spec, ["q", "qd", "qdd"])
+        Min = [tr.inp("in.Minv(%d)" % i) for i in range(n * n)]
+        Minv = [[Min[n * c + r] if r <= c else None for c in range(n)] for r in range(n)]
+        qdd = ins["qdd"]
+    else:
+        tr, ins, g, X, I = _setup(spec, ["q", "qd", "u"])
+        Minv = alg.direct_minv(tr, spec, X, I)
+        c, v, a, f = alg.rnea(tr, spec, X, I, ins["qd"], None, g)
+        qdd = alg.fd_finish(tr, spec, Minv, ins["u"], c)
+    c, v, a, f = alg.rnea(tr, spec, X, I, ins["qd"], qdd, g)
+    dq, dqd = alg.rnea_grad(tr, spec, X, I, ins["qd"], v, a, f, g)
+    oq, oqd = alg.fd_grad_finish(tr, spec, Minv, dq, dqd)
+    _out_grad(tr, spec, oq, oqd)
+    return tr
+
+
+# ------------------------------------------------------------------------------------------------
+# pointer-style ``_inner`` bodies (API parity with the reference's ALGORITHM_inner tier)
+# ------------------------------------------------------------------------------------------------
+def inner_inverse_dynamics(spec, compute_c, use_qdd):
+    """inverse_dynamics_inner / inverse_dynamics_inner_vaf: writes s_vaf (and s_c)."""
+    tr, ins, g, X, I = _setup(spec, ["q", "qd"] + (["qdd"] if use_qdd else []), "inner")
+    c, v, a, f = alg.rnea(tr, spec, X, I, ins["qd"], ins.get("qdd"), g)
+    n = spec.n
+    if compute_c:
+        for j in range(n):
+            tr.out("s_c[%d]" % j, c[j])
+    for blk, arr in enumerate((v, a, f)):
+        for j in range(n):
+            for r in range(6):
+                tr.out("s_vaf[%d]" % (6 * n * blk + 6 * j + r), arr[j][r])
+    return tr
+
+
+def inner_direct_minv(spec):
+    tr, ins, g, X, I = _setup(spec, ["q"], "inner")
+    Minv = alg.direct_minv(tr, spec, X, I)
+    n = spec.n
+    for col in range(n):
+        for row in range(n):
+            tr.out("s_Minv[%d]" % (n * col + row), Minv[row][col] if row <= col else tr.zero())
+    return tr
+
+
+def inner_forward_dynamics_finish(spec):
+    tr = Tracer()
+    n = spec.n
+    u = [tr.inp("s_u[%d]" % j) for j in range(n)]
+    c = [tr.inp("s_c[%d]" % j) for j in range(n)]
+    Min = [tr.inp("s_Minv[%d]" % i) for i in range(n * n)]
+    Minv = [[Min[n * cc + r] if r <= cc else None for cc in range(n)] for r in range(n)]
+    qdd = alg.fd_finish(tr, spec, Minv, u, c)
+    for j in range(n):
+        tr.out("s_qdd[%d]" % j, qdd[j])
+    return tr
+
+
+def inner_forward_dynamics(spec):
+    tr, ins, g, X, I = _setup(spec, ["q", "qd", "u"], "inner")
+    Minv = alg.direct_minv(tr, spec, X, I)
+    c, v, a, f = alg.rnea(tr, spec, X, I, ins["qd"], None, g)
+    qdd = alg.fd_finish(tr, spec, Minv, ins["u"], c)
+    for j in range(spec.n):
+        tr.out("s_qdd[%d]" % j, qdd[j])
+    return tr
+
+
+def inner_inverse_dynamics_gradient(spec):
+    """inverse_dynamics_gradient_inner: v, a, f come in through s_vaf (as in the reference)."""
+    tr, ins, g, X, I = _setup(spec, ["q", "qd"], "inner")
+    n = spec.n
+    v = [[tr.inp("s_vaf[%d]" % (6 * j + r)) for r in range(6)] for j in range(n)]
+    a = [[tr.inp("s_vaf[%d]" % (6 * n + 6 * j + r)) for r in range(6)] for j in range(n)]
+    f = [[tr.inp("s_vaf[%d]" % (12 * n + 6 * j + r)) for r in range(6)] for j in range(n)]
+    dq, dqd = alg.rnea_grad(tr, spec, X, I, ins["qd"], v, a, f, g)
+    for col in range(n):
+        for row in range(n):
+            tr.out("s_dc_du[%d]" % (n * col + row), dq[row][col])
+    for col in range(n):
+        for row in range(n):
+            tr.out("s_dc_du[%d]" % (n * n + n * col + row), dqd[row][col])
+    return tr

@@ -1,0 +1,360 @@
+"""Scalar straight-line tracer: the generation-time specialiser behind every emitted ``_inner``.
+
+The reference emits loops over dense 6x6 products whose bounds and offsets are literals
+(``algorithms/_inverse_dynamics.py:151-167``: ``dot_prod<T,6,6,1>`` over full rows even though half
+of X is structurally zero).  Here the algorithm is *run once in Python* on symbolic scalars:
+
+* a value is either a Python float (known at generation time) or a signed reference to an IR node;
+* ``0*x``, ``1*x``, ``x+0`` and constant arithmetic fold away, so structural zeros / +-1 entries of
+  X_j(q) and I_j never reach the device code;
+* nodes are hash-consed (common sub-expressions such as the ``X_j v_parent`` shared by the two RNEA
+  passes of the forward-dynamics gradient are emitted once);
+* dead nodes are dropped at emission (only what reaches an output survives).
+
+The result is one basic block of ``fma``/``mul``/``add`` on named temporaries in the compute type
+``C`` -- one wavefront lane executes it for one configuration; there is no cross-lane traffic and no
+barrier inside an ``_inner``.
+"""
+import math
+
+
+class V:
+    """A traced scalar: ``ref`` is a Python float or a signed node index (+k / -k, k >= 1)."""
+    __slots__ = ("tr", "ref")
+
+    def __init__(self, tr, ref):
+        self.tr = tr
+        self.ref = ref
+
+    # --- helpers -------------------------------------------------------------------------------
+    def is_const(self):
+        return isinstance(self.ref, float)
+
+    def is_zero(self):
+        return isinstance(self.ref, float) and self.ref == 0.0
+
+    def const(self):
+        return self.ref
+
+    def _lift(self, o):
+        if isinstance(o, V):
+            return o
+        return V(self.tr, float(o))
+
+    # --- arithmetic ------------------------------------------------------------------------------
+    def __neg__(self):
+        return V(self.tr, -self.ref)
+
+    def __add__(self, o):
+        return self.tr.add(self, self._lift(o))
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        return self.tr.add(self, -self._lift(o))
+
+    def __rsub__(self, o):
+        return self.tr.add(self._lift(o), -self)
+
+    def __mul__(self, o):
+        return self.tr.mul(self, self._lift(o))
+
+    __rmul__ = __mul__
+
+    def __repr__(self):
+        return "V(%r)" % (self.ref,)
+
+
+class Tracer:
+    def __init__(self):
+        self.nodes = [None]      # 1-based; each node: (op, a, b, c) with operand refs / payload
+        self.cse = {}
+        self.outputs = []        # (dst_expr, ref)
+        self.comments = {}       # node index -> comment emitted before it
+
+    # --- leaf constructors ---------------------------------------------------------------------
+    def const(self, x):
+        return V(self, float(x))
+
+    def zero(self):
+        return V(self, 0.0)
+
+    def inp(self, expr):
+        """Load of an input element (a C expression such as ``s_q[3]``)."""
+        return V(self, self._node(("in", expr, None, None)))
+
+    def _node(self, key):
+        idx = self.cse.get(key)
+        if idx is None:
+            self.nodes.append(key)
+            idx = len(self.nodes) - 1
+            self.cse[key] = idx
+        return idx
+
+    def comment(self, text):
+        self.comments.setdefault(len(self.nodes), []).append(text)
+
+    # --- operations --------------------------------------------------------------------------------
+    def mul(self, a, b):
+        ra, rb = a.ref, b.ref
+        if isinstance(ra, float) and isinstance(rb, float):
+            return V(self, ra * rb)
+        if isinstance(ra, float):
+            ra, rb = rb, ra
+        # now ra is a node ref; rb may be a float
+        if isinstance(rb, float):
+            if rb == 0.0:
+                return V(self, 0.0)
+            if rb == 1.0:
+                return V(self, ra)
+            if rb == -1.0:
+                return V(self, -ra)
+            sign = (1 if ra > 0 else -1) * (1 if rb > 0 else -1)
+            return V(self, sign * self._node(("mul", abs(ra), abs(rb), None)))
+        sign = (1 if ra > 0 else -1) * (1 if rb > 0 else -1)
+        x, y = sorted((abs(ra), abs(rb)))
+        return V(self, sign * self._node(("mul", x, y, None)))
+
+    def add(self, a, b):
+        ra, rb = a.ref, b.ref
+        if isinstance(ra, float) and isinstance(rb, float):
+            return V(self, ra + rb)
+        if isinstance(ra, float):
+            ra, rb = rb, ra
+        if isinstance(rb, float):
+            if rb == 0.0:
+                return V(self, ra)
+            if ra < 0:  # -(x) + c == -(x - c)
+                return V(self, -self._node(("add", -ra, -rb, None)))
+            return V(self, self._node(("add", ra, rb, None)))
+        if ra == -rb:
+            return V(self, 0.0)
+        if abs(ra) > abs(rb):
+            ra, rb = rb, ra
+        if ra < 0:
+            return V(self, -self._node(("add", -ra, -rb, None)))
+        return V(self, self._node(("add", ra, rb, None)))
+
+    def fma(self, a, b, c):
+        """a*b + c with folding."""
+        ra, rb, rc = a.ref, b.ref, c.ref
+        if isinstance(rc, float) and rc == 0.0:
+            return self.mul(a, b)
+        if isinstance(ra, float) and isinstance(rb, float):
+            return self.add(V(self, ra * rb), c)
+        if isinstance(ra, float):
+            ra, rb = rb, ra
+        if isinstance(rb, float):
+            if rb == 0.0:
+                return c
+            if rb == 1.0:
+                return self.add(V(self, ra), c)
+            if rb == -1.0:
+                return self.add(V(self, -ra), c)
+            sign = (1 if ra > 0 else -1) * (1 if rb > 0 else -1)
+            x, y = abs(ra), abs(rb)
+        else:
+            sign = (1 if ra > 0 else -1) * (1 if rb > 0 else -1)
+            x, y = sorted((abs(ra), abs(rb)))
+        # sign*(x*y) + rc ; canonical form keeps the product positive
+        if sign > 0:
+            return V(self, self._node(("fma", x, y, rc)))
+        return V(self, -self._node(("fma", x, y, -rc)))
+
+    def dot(self, pairs, init=None):
+        """sum_i a_i*b_i (+ init) as an fma chain; zero terms vanish."""
+        acc = init if init is not None else V(self, 0.0)
+        for (a, b) in pairs:
+            a = a if isinstance(a, V) else V(self, float(a))
+            b = b if isinstance(b, V) else V(self, float(b))
+            acc = self.fma(a, b, acc)
+        return acc
+
+    def rcp(self, a):
+        if isinstance(a.ref, float):
+            return V(self, 1.0 / a.ref)
+        sign = 1 if a.ref > 0 else -1
+        return V(self, sign * self._node(("rcp", abs(a.ref), None, None)))
+
+    def sin(self, a):
+        if isinstance(a.ref, float):
+            return V(self, math.sin(a.ref))
+        sign = 1 if a.ref > 0 else -1
+        return V(self, sign * self._node(("sin", abs(a.ref), None, None)))
+
+    def cos(self, a):
+        if isinstance(a.ref, float):
+            return V(self, math.cos(a.ref))
+        return V(self, self._node(("cos", abs(a.ref), None, None)))
+
+    def out(self, dst_expr, val):
+        val = val if isinstance(val, V) else V(self, float(val))
+        self.outputs.append((dst_expr, val.ref))
+
+    # --- analysis / emission ---------------------------------------------------------------------
+    def live_nodes(self):
+        live = [False] * len(self.nodes)
+        stack = [abs(r) for (_, r) in self.outputs if not isinstance(r, float)]
+        while stack:
+            k = stack.pop()
+            if live[k]:
+                continue
+            live[k] = True
+            op, a, b, c = self.nodes[k]
+            if op == "in":
+                continue
+            for r in (a, b, c):
+                if r is not None and not isinstance(r, float) and not live[abs(r)]:
+                    stack.append(abs(r))
+        return live
+
+    def op_counts(self):
+        live = self.live_nodes()
+        counts = {}
+        for k in range(1, len(self.nodes)):
+            if live[k]:
+                counts[self.nodes[k][0]] = counts.get(self.nodes[k][0], 0) + 1
+        return counts
+
+    def flops(self):
+        c = self.op_counts()
+        return 2 * c.get("fma", 0) + c.get("mul", 0) + c.get("add", 0)
+
+    @staticmethod
+    def _lit(x):
+        if x == int(x) and abs(x) < 1e9:
+            return "(C)%d" % int(x)
+        return "(C)%s" % repr(float(x))
+
+    def _opnd(self, r):
+        if isinstance(r, float):
+            return self._lit(r)
+        return ("t%d" % r) if r > 0 else ("-t%d" % (-r))
+
+    def emit(self, indent="    ", order="demand", store=None, after_store=None):
+        """C++ statements (compute type ``C``, storage type ``T``) for all live nodes + output stores.
+
+        order="demand": outputs are visited in order and each pulls in (post-order) whatever it still
+        needs, so a value is computed close to its first use -- this keeps live ranges short in the
+        long matrix-product tails.  order="creation": nodes in trace order, all stores at the end.
+        store(dst, value_expr) -> statement; after_store(i) -> optional extra statement after output i.
+        """
+        live = self.live_nodes()
+        if store is None:
+            store = lambda dst, val: "%s = (T)(%s);" % (dst, val)
+        trig_args = {}
+        for k in range(1, len(self.nodes)):
+            if live[k] and self.nodes[k][0] in ("sin", "cos"):
+                trig_args.setdefault(self.nodes[k][1], {})[self.nodes[k][0]] = k
+        emitted = [False] * len(self.nodes)
+        lines = []
+
+        def emit_node(k):
+            op, a, b, c = self.nodes[k]
+            emitted[k] = True
+            if op == "in":
+                lines.append("%sconst C t%d = (C)%s;" % (indent, k, a))
+            elif op == "mul":
+                lines.append("%sconst C t%d = %s * %s;" % (indent, k, self._opnd(a), self._opnd(b)))
+            elif op == "add":
+                if not isinstance(b, float) and b < 0:
+                    lines.append("%sconst C t%d = %s - t%d;" % (indent, k, self._opnd(a), -b))
+                elif isinstance(b, float) and b < 0:
+                    lines.append("%sconst C t%d = %s - %s;" % (indent, k, self._opnd(a), self._lit(-b)))
+                else:
+                    lines.append("%sconst C t%d = %s + %s;" % (indent, k, self._opnd(a), self._opnd(b)))
+            elif op == "fma":
+                lines.append("%sconst C t%d = grid_fma(%s, %s, %s);" % (indent, k, self._opnd(a), self._opnd(b), self._opnd(c)))
+            elif op == "rcp":
+                lines.append("%sconst C t%d = (C)1 / %s;" % (indent, k, self._opnd(a)))
+            elif op in ("sin", "cos"):
+                pair = trig_args[a]
+                if "sin" in pair and "cos" in pair:
+                    emitted[pair["sin"]] = True
+                    emitted[pair["cos"]] = True
+                    lines.append("%sC t%d, t%d; grid_sincos(%s, &t%d, &t%d);" % (
+                        indent, pair["sin"], pair["cos"], self._opnd(a), pair["sin"], pair["cos"]))
+                else:
+                    lines.append("%sconst C t%d = grid_%s(%s);" % (indent, k, op, self._opnd(a)))
+            else:
+                raise AssertionError(op)
+
+        def deps(k):
+            op, a, b, c = self.nodes[k]
+            if op == "in":
+                return ()
+            return tuple(abs(r) for r in (a, b, c) if r is not None and not isinstance(r, float))
+
+        if order == "creation":
+            for k in range(1, len(self.nodes)):
+                if live[k] and not emitted[k]:
+                    emit_node(k)
+            for i, (dst, r) in enumerate(self.outputs):
+                lines.append(indent + store(dst, self._opnd(r)))
+                if after_store is not None:
+                    extra = after_store(i)
+                    if extra:
+                        lines.append(indent + extra)
+            return lines
+        for i, (dst, r) in enumerate(self.outputs):
+            if not isinstance(r, float):
+                stack = [(abs(r), False)]
+                while stack:
+                    k, expanded = stack.pop()
+                    if emitted[k]:
+                        continue
+                    if expanded:
+                        emit_node(k)
+                        continue
+                    stack.append((k, True))
+                    for d in reversed(deps(k)):
+                        if not emitted[d]:
+                            stack.append((d, False))
+            lines.append(indent + store(dst, self._opnd(r)))
+            if after_store is not None:
+                extra = after_store(i)
+                if extra:
+                    lines.append(indent + extra)
+        return lines
+
+    def evaluate(self, inputs, dtype="float64"):
+        """Interpret the live part of the trace with numpy (batched).  Used by the CPU-side tests to
+        check a trace against the oracle and to study fp32 round-off without a compiler or a GPU.
+
+        inputs: dict input-expression -> array (K,).  dtype float32 emulates fp32 storage with fused
+        multiply-add (product and sum formed in float64, rounded once to float32).
+        Returns the list of output arrays in ``self.outputs`` order.
+        """
+        import numpy as np
+        dt = np.dtype(dtype)
+        live = self.live_nodes()
+        val = [None] * len(self.nodes)
+
+        def get(r):
+            if isinstance(r, float):
+                return np.float64(r) if dt == np.float64 else np.float64(np.float32(r))
+            x = val[abs(r)]
+            return x if r > 0 else -x
+
+        def rnd(x):
+            return x if dt == np.float64 else x.astype(np.float32).astype(np.float64)
+
+        for k in range(1, len(self.nodes)):
+            if not live[k]:
+                continue
+            op, a, b, c = self.nodes[k]
+            if op == "in":
+                val[k] = rnd(np.asarray(inputs[a], dtype=np.float64))
+            elif op == "mul":
+                val[k] = rnd(get(a) * get(b))
+            elif op == "add":
+                val[k] = rnd(get(a) + get(b))
+            elif op == "fma":
+                val[k] = rnd(get(a) * get(b) + get(c))
+            elif op == "rcp":
+                val[k] = rnd(1.0 / get(a))
+            elif op == "sin":
+                val[k] = rnd(np.sin(get(a)))
+            elif op == "cos":
+                val[k] = rnd(np.cos(get(a)))
+        return [get(r) if not isinstance(r, float) else np.float64(r) for (_, r) in self.outputs]

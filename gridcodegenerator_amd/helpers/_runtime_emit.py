@@ -1,0 +1,398 @@
+"""Emission of the non-algorithmic parts of grid.hip.h: includes, error check, constants, structs,
+model-constant upload, gridData allocation, lane math helpers and the wave-level LDS staging that
+turns the AoS boundary layout into lane-private registers and back.
+
+Boundary contract reproduced from the reference (names, argument order, buffer layouts):
+GRiDCodeGenerator.py:68-114 (constants + structs), :116-153 (init_gridData), :155-203
+(init_grid / close_grid), :205-218 (gpuAssert), helpers/_topology_helpers.py:3-54 (init_XImats),
+:217-258 (init_topology_helpers), :365-380 (init_robotModel).  The hardware mapping is new.
+"""
+import numpy as np
+
+WAVE = 64
+
+
+def _fmt(x):
+    x = float(x)
+    if x == int(x) and abs(x) < 1e15:
+        return "%d" % int(x)
+    return repr(x)
+
+
+class RuntimeEmitMixin:
+    # ------------------------------------------------------------------------------------------
+    def gen_add_includes(self, use_thread_group=False):
+        self.gen_add_code_lines([
+            "#pragma once",
+            "#include <assert.h>",
+            "#include <math.h>",
+            "#include <stdio.h>",
+            "#include <stdlib.h>",
+            "#include <time.h>",
+            "#include <hip/hip_runtime.h>",
+            "// single kernel timing helper code",
+            "#define time_delta_us_timespec(start,end) (1e6*static_cast<double>(end.tv_sec - start.tv_sec)+1e-3*static_cast<double>(end.tv_nsec - start.tv_nsec))",
+            "",
+        ])
+
+    def gen_add_gpu_err(self):
+        self.gen_add_func_doc("Check for runtime errors using the HIP API",
+                              ["Default behaviour mirrors the reference (print, reset, exit).",
+                               "Compile with -DGRID_ERRORS_RETURN to record the first error instead of exiting",
+                               "(a ctypes / C-ABI caller must survive): query it with grid_first_error()."])
+        self.gen_add_code_lines([
+            "#ifndef GRID_HIP_ERRCHK_DEFINED",
+            "#define GRID_HIP_ERRCHK_DEFINED",
+            "inline hipError_t &grid_first_error(){static thread_local hipError_t err = hipSuccess; return err;}",
+            "inline const char *&grid_first_error_where(){static thread_local const char *where = \"\"; return where;}",
+            "inline int &grid_first_error_line(){static thread_local int line = 0; return line;}",
+            "__host__ inline",
+            "void gpuAssert(hipError_t code, const char *file, const int line, bool abort=true){",
+            "    if (code != hipSuccess){",
+            "#ifdef GRID_ERRORS_RETURN",
+            "        if (grid_first_error() == hipSuccess){grid_first_error() = code; grid_first_error_where() = file; grid_first_error_line() = line;}",
+            "        (void)abort;",
+            "#else",
+            "        fprintf(stderr,\"GPUassert: %s %s %d\\n\", hipGetErrorString(code), file, line);",
+            "        if (abort){hipDeviceReset(); exit(code);}",
+            "#endif",
+            "    }",
+            "}",
+            "#define gpuErrchk(err) {gpuAssert(err, __FILE__, __LINE__);}",
+            "#endif",
+            "",
+        ])
+        if self.gen_print_mat:
+            for const in ("", "const "):
+                self.gen_add_code_lines([
+                    "template <typename T, int M, int N>",
+                    "__host__ __device__",
+                    "void printMat(%sT *A, int lda){" % const,
+                    "    for(int i=0; i<M; i++){",
+                    "        for(int j=0; j<N; j++){printf(\"%.4f \",(double)A[i + lda*j]);}",
+                    "        printf(\"\\n\");",
+                    "    }",
+                    "}",
+                    "",
+                ])
+
+    # ------------------------------------------------------------------------------------------
+    def lds_per_wave(self, alg):
+        """LDS elements one wavefront needs for algorithm ``alg`` (input staging vs output chunk)."""
+        lay = self.io_layout[alg]
+        need = [WAVE * self._pad(nin) for (_, nin) in lay["inputs"]]
+        need.append(WAVE * self._pad(lay["chunk"]))
+        return max(need)
+
+    @staticmethod
+    def _pad(x):
+        """Odd per-lane stride => lane L at L*stride hits 64 distinct banks (conflict-free ds_read/ds_write b32)."""
+        return x if x % 2 == 1 else x + 1
+
+    def gen_add_constants_helpers(self):
+        n = self.spec.n
+        waves = self.suggested_threads // WAVE
+        self.gen_add_code_lines([
+            "const int NUM_JOINTS = %d;" % n,
+            "// lane-per-configuration: one wavefront (64 lanes) stages 64 configurations through LDS;",
+            "// <ALG>_DYNAMIC_SHARED_MEM_COUNT is what a block of SUGGESTED_THREADS threads needs (in T elements)",
+            "const int GRID_WAVE_SIZE = %d;" % WAVE,
+            "const int ID_DYNAMIC_SHARED_MEM_COUNT = %d;" % (waves * self.lds_per_wave("ID")),
+            "const int MINV_DYNAMIC_SHARED_MEM_COUNT = %d;" % (waves * self.lds_per_wave("MINV")),
+            "const int FD_DYNAMIC_SHARED_MEM_COUNT = %d;" % (waves * self.lds_per_wave("FD")),
+            "const int ID_DU_DYNAMIC_SHARED_MEM_COUNT = %d;" % (waves * self.lds_per_wave("ID_DU")),
+            "const int FD_DU_DYNAMIC_SHARED_MEM_COUNT = %d;" % (waves * self.lds_per_wave("FD_DU")),
+            "const int ID_DU_MAX_SHARED_MEM_COUNT = %d;" % (waves * self.lds_per_wave("ID_DU")),
+            "const int FD_DU_MAX_SHARED_MEM_COUNT = %d;" % (waves * self.lds_per_wave("FD_DU")),
+            "const int SUGGESTED_THREADS = %d;" % self.suggested_threads,
+            "const int SUGGESTED_MAX_BLOCKS = %d; // 256 CUs x 8; larger batches grid-stride" % self.suggested_max_blocks,
+            "const int XIMATS_LANE_COUNT = %d; // per-lane s_XImats: [sin(q_j) | cos(q_j)]" % (2 * n),
+            "const int XIMATS_MODEL_COUNT = %d; // d_robotModel->d_XImats: X constants then I, as in the reference" % (72 * n),
+            "const int TOPOLOGY_HELPERS_COUNT = %d;" % self.spec.topology_helpers_size(),
+        ])
+        self.gen_add_code_line("// Define custom structs")
+        self.gen_add_code_lines([
+            "template <typename T>",
+            "struct robotModel {",
+            "    T *d_XImats;",
+            "    int *d_topology_helpers;",
+            "};",
+            "template <typename T>",
+            "struct gridData {",
+            "    // GPU INPUTS",
+            "    T *d_q_qd_u;",
+            "    T *d_q_qd;",
+            "    T *d_q;",
+            "    // CPU INPUTS",
+            "    T *h_q_qd_u;",
+            "    T *h_q_qd;",
+            "    T *h_q;",
+            "    // GPU OUTPUTS",
+            "    T *d_c;",
+            "    T *d_Minv;",
+            "    T *d_qdd;",
+            "    T *d_dc_du;",
+            "    T *d_df_du;",
+            "    // CPU OUTPUTS",
+            "    T *h_c;",
+            "    T *h_Minv;",
+            "    T *h_qdd;",
+            "    T *h_dc_du;",
+            "    T *h_df_du;",
+            "};",
+            "",
+        ])
+
+    # ------------------------------------------------------------------------------------------
+    def gen_lane_helpers(self):
+        """Lane math + accessors + wave-level LDS staging (new in the MI355X design)."""
+        compute_f = "double" if self.precision == "fp64" else "float"
+        self.gen_add_code_lines([
+            "// ---- lane math: compute type C (generation-time default for T=float: %s) ----" % compute_f,
+            "template <typename T> struct grid_compute {typedef T type;};",
+            "template <> struct grid_compute<float> {typedef %s type;};" % compute_f,
+            "__host__ __device__ __forceinline__ float grid_fma(float a, float b, float c){return __builtin_fmaf(a,b,c);}",
+            "__host__ __device__ __forceinline__ double grid_fma(double a, double b, double c){return __builtin_fma(a,b,c);}",
+        ])
+        if self.trig == "f64":
+            self.gen_add_code_lines([
+                "// sin/cos evaluated in double then rounded, as the reference does (helpers/_topology_helpers.py:127-128)",
+                "__host__ __device__ __forceinline__ void grid_sincos(float x, float *s, float *c){double sd, cd; sincos((double)x, &sd, &cd); *s = (float)sd; *c = (float)cd;}",
+            ])
+        else:
+            self.gen_add_code_lines([
+                "__host__ __device__ __forceinline__ void grid_sincos(float x, float *s, float *c){sincosf(x, s, c);}",
+            ])
+        self.gen_add_code_lines([
+            "__host__ __device__ __forceinline__ void grid_sincos(double x, double *s, double *c){sincos(x, s, c);}",
+            "__host__ __device__ __forceinline__ float grid_sin(float x){float s, c; grid_sincos(x, &s, &c); return s;}",
+            "__host__ __device__ __forceinline__ float grid_cos(float x){float s, c; grid_sincos(x, &s, &c); return c;}",
+            "__host__ __device__ __forceinline__ double grid_sin(double x){return sin(x);}",
+            "__host__ __device__ __forceinline__ double grid_cos(double x){return cos(x);}",
+            "",
+            "// ---- accessors the traced cores are written against ----",
+            "template <typename T>",
+            "struct grid_in_ptrs {",
+            "    const T *q_; const T *qd_; const T *u_; const T *qdd_; const T *Minv_;",
+            "    __host__ __device__ __forceinline__ T q(int i) const {return q_[i];}",
+            "    __host__ __device__ __forceinline__ T qd(int i) const {return qd_[i];}",
+            "    __host__ __device__ __forceinline__ T u(int i) const {return u_[i];}",
+            "    __host__ __device__ __forceinline__ T qdd(int i) const {return qdd_[i];}",
+            "    __host__ __device__ __forceinline__ T Minv(int i) const {return Minv_[i];}",
+            "};",
+            "template <typename T>",
+            "struct grid_out_ptr {",
+            "    T *p_;",
+            "    __host__ __device__ __forceinline__ void put(int i, T v){p_[i] = v;}",
+            "};",
+            "",
+            "// ---- wave-level staging: 64 lanes <-> 64 consecutive configurations, no block barrier ----",
+            "__device__ __forceinline__ void grid_wave_sync(){",
+            "    __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\");",
+            "    __builtin_amdgcn_wave_barrier();",
+            "    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");",
+            "}",
+            "/**",
+            " * Load N values for each of the wave's 64 configurations (k0 .. k0+63, row stride `stride`).",
+            " * staged: flat coalesced global reads -> LDS (per-lane stride NPAD, odd => conflict free) -> registers.",
+            " * !staged: each lane reads its own row directly (any block shape; not coalesced).",
+            " * Lanes past NUM_TIMESTEPS receive zeros (staged) / a clamped row (direct) and never store.",
+            " */",
+            "template <typename T, int N, int NPAD>",
+            "__device__ __forceinline__ void grid_load_tile(T *dst, const T *d_src, const int stride, const int k0, const int lane,",
+            "                                               const int NUM_TIMESTEPS, T *s_wave, const bool staged){",
+            "    if (staged){",
+            "        const int nvalid = min(GRID_WAVE_SIZE, NUM_TIMESTEPS - k0);",
+            "        #pragma unroll",
+            "        for (int t = 0; t < N; t++){",
+            "            const int f = t*GRID_WAVE_SIZE + lane; const int cfg = f / N; const int i = f - cfg*N;",
+            "            s_wave[cfg*NPAD + i] = (cfg < nvalid) ? d_src[(size_t)(k0 + cfg)*stride + i] : static_cast<T>(0);",
+            "        }",
+            "        grid_wave_sync();",
+            "        #pragma unroll",
+            "        for (int i = 0; i < N; i++){dst[i] = s_wave[lane*NPAD + i];}",
+            "        grid_wave_sync();",
+            "    }",
+            "    else {",
+            "        const int k = min(k0 + lane, NUM_TIMESTEPS - 1);",
+            "        #pragma unroll",
+            "        for (int i = 0; i < N; i++){dst[i] = d_src[(size_t)k*stride + i];}",
+            "    }",
+            "}",
+            "/**",
+            " * Output sink of a kernel: put(i, v) in increasing i.  Values collect in LDS CH at a time and every full",
+            " * chunk is written out flat (consecutive lanes -> consecutive addresses inside each configuration's run of",
+            " * CH values), so the N_OUT*64 results of a wave leave as wide contiguous stores instead of 64-way strided ones.",
+            " */",
+            "template <typename T, int N_OUT, int CH, int CHPAD>",
+            "struct grid_out_staged {",
+            "    T *s_wave; T *d_dst; int k0; int lane; int NUM_TIMESTEPS; bool staged;",
+            "    __device__ __forceinline__ void flush(const int chunk){",
+            "        const int base = chunk*CH; const int len = (N_OUT - base < CH) ? (N_OUT - base) : CH;",
+            "        const int nvalid = min(GRID_WAVE_SIZE, NUM_TIMESTEPS - k0);",
+            "        grid_wave_sync();",
+            "        #pragma unroll",
+            "        for (int t = 0; t < len; t++){",
+            "            const int f = t*GRID_WAVE_SIZE + lane; const int cfg = f / len; const int i = f - cfg*len;",
+            "            if (cfg < nvalid){d_dst[(size_t)(k0 + cfg)*N_OUT + base + i] = s_wave[cfg*CHPAD + i];}",
+            "        }",
+            "        grid_wave_sync();",
+            "    }",
+            "    __device__ __forceinline__ void put(const int i, const T v){",
+            "        if (staged){",
+            "            s_wave[lane*CHPAD + (i % CH)] = v;",
+            "            if (((i + 1) % CH) == 0 || i == N_OUT - 1){flush(i / CH);}",
+            "        }",
+            "        else if (k0 + lane < NUM_TIMESTEPS){d_dst[(size_t)(k0 + lane)*N_OUT + i] = v;}",
+            "    }",
+            "};",
+            "/** Wave/tile bookkeeping shared by every kernel (flat thread ids; any grid/block shape is accepted). */",
+            "struct grid_tile_iter {",
+            "    int lane; int k0_first; int k0_step; bool staged; int wave_in_block;",
+            "    __device__ __forceinline__ grid_tile_iter(){",
+            "        const int nthreads = blockDim.x*blockDim.y*blockDim.z;",
+            "        const int tid = threadIdx.x + blockDim.x*(threadIdx.y + blockDim.y*threadIdx.z);",
+            "        const int nblocks = gridDim.x*gridDim.y*gridDim.z;",
+            "        const int bid = blockIdx.x + gridDim.x*(blockIdx.y + gridDim.y*blockIdx.z);",
+            "        lane = tid & (GRID_WAVE_SIZE - 1); wave_in_block = tid / GRID_WAVE_SIZE;",
+            "        k0_first = bid*nthreads + (tid - lane); k0_step = nblocks*nthreads;",
+            "        // LDS staging needs whole waves and a block no larger than the LDS was sized for",
+            "        staged = ((nthreads % GRID_WAVE_SIZE) == 0) && (nthreads <= SUGGESTED_THREADS);",
+            "    }",
+            "};",
+            "",
+        ])
+
+    # ------------------------------------------------------------------------------------------
+    def gen_init_topology_helpers(self):
+        row = self.spec.topology_helpers_row()
+        if not row:
+            self.gen_add_code_lines(["//", "// Topology Helpers not needed!", "//",
+                                     "template <typename T>", "__host__",
+                                     "int *init_topology_helpers(){return nullptr;}", ""])
+            return
+        self.gen_add_func_doc("Initializes the topology_helpers in GPU memory",
+                              ["Same integer table as the reference (parent_inds, [S_inds,] num_ancestors, num_subtree,",
+                               "running sums); the lane-per-configuration kernels bake topology into straight-line code and",
+                               "never read it -- it is uploaded for API parity and for callers that index with it."],
+                              [], "A pointer to the topology_helpers memory in the GPU")
+        self.gen_add_code_lines(["template <typename T>", "__host__", "int *init_topology_helpers() {"], True)
+        self.gen_add_code_line("int h_topology_helpers[] = {" + ",".join(str(v) for v in row) + "};")
+        size = len(row)
+        self.gen_add_code_line("int *d_topology_helpers; gpuErrchk(hipMalloc((void**)&d_topology_helpers,%d*sizeof(int)));" % size)
+        self.gen_add_code_line("gpuErrchk(hipMemcpy(d_topology_helpers,h_topology_helpers,%d*sizeof(int),hipMemcpyHostToDevice));" % size)
+        self.gen_add_code_line("return d_topology_helpers;")
+        self.gen_add_end_function()
+
+    def gen_init_XImats(self, include_base_inertia=False):
+        table = self.spec.XImats_table()
+        self.gen_add_func_doc("Initializes the Xmats and Imats in GPU memory",
+                              ["Memory order is X[0...N], I[0...N] (column-major 6x6 blocks; theta-dependent X entries are 0)",
+                               "The emitted kernels fold these constants into their instruction streams; the table is uploaded",
+                               "for API parity with the reference's robotModel and for user kernels."],
+                              [], "A pointer to the XI memory in the GPU")
+        self.gen_add_code_lines(["template <typename T>", "__host__", "T* init_XImats() {"], True)
+        size = len(table)
+        self.gen_add_code_line("static const double h_XImats_d[%d] = {" % size)
+        for i in range(0, size, 6):
+            self.gen_add_code_line("    " + ", ".join(_fmt(v) for v in table[i:i + 6]) + ("," if i + 6 < size else ""))
+        self.gen_add_code_line("};")
+        self.gen_add_code_line("T *h_XImats = (T *)malloc(%d*sizeof(T));" % size)
+        self.gen_add_code_line("for (int i = 0; i < %d; i++){h_XImats[i] = static_cast<T>(h_XImats_d[i]);}" % size)
+        self.gen_add_code_line("T *d_XImats; gpuErrchk(hipMalloc((void**)&d_XImats,%d*sizeof(T)));" % size)
+        self.gen_add_code_line("gpuErrchk(hipMemcpy(d_XImats,h_XImats,%d*sizeof(T),hipMemcpyHostToDevice));" % size)
+        self.gen_add_code_line("free(h_XImats);")
+        self.gen_add_code_line("return d_XImats;")
+        self.gen_add_end_function()
+
+    def gen_init_robotModel(self):
+        self.gen_add_func_doc("Initializes the robotModel helpers in GPU memory", [], [], "A pointer to the robotModel struct")
+        self.gen_add_code_lines(["template <typename T>", "__host__", "robotModel<T>* init_robotModel() {"], True)
+        self.gen_add_code_lines([
+            "robotModel<T> h_robotModel;",
+            "h_robotModel.d_XImats = init_XImats<T>();",
+            "h_robotModel.d_topology_helpers = init_topology_helpers<T>();",
+            "robotModel<T> *d_robotModel; gpuErrchk(hipMalloc((void**)&d_robotModel,sizeof(robotModel<T>)));",
+            "gpuErrchk(hipMemcpy(d_robotModel,&h_robotModel,sizeof(robotModel<T>),hipMemcpyHostToDevice));",
+            "return d_robotModel;",
+        ])
+        self.gen_add_end_function()
+
+    def gen_init_gridData(self):
+        body = [
+            "gridData<T> *hd_data = (gridData<T> *)malloc(sizeof(gridData<T>));",
+            "const size_t K = (size_t)NUM_TIMESTEPS; const size_t N = NUM_JOINTS;",
+            "// first the input variables on the GPU",
+            "gpuErrchk(hipMalloc((void**)&hd_data->d_q_qd_u, 3*N*K*sizeof(T)));",
+            "gpuErrchk(hipMalloc((void**)&hd_data->d_q_qd, 2*N*K*sizeof(T)));",
+            "gpuErrchk(hipMalloc((void**)&hd_data->d_q, N*K*sizeof(T)));",
+            "// and the CPU (pinned, so the H2D/D2H copies of the host wrappers run at full PCIe rate)",
+            "gpuErrchk(hipHostMalloc((void**)&hd_data->h_q_qd_u, 3*N*K*sizeof(T)));",
+            "gpuErrchk(hipHostMalloc((void**)&hd_data->h_q_qd, 2*N*K*sizeof(T)));",
+            "gpuErrchk(hipHostMalloc((void**)&hd_data->h_q, N*K*sizeof(T)));",
+            "// then the GPU outputs",
+            "gpuErrchk(hipMalloc((void**)&hd_data->d_c, N*K*sizeof(T)));",
+            "gpuErrchk(hipMalloc((void**)&hd_data->d_Minv, N*N*K*sizeof(T)));",
+            "gpuErrchk(hipMalloc((void**)&hd_data->d_qdd, N*K*sizeof(T)));",
+            "gpuErrchk(hipMalloc((void**)&hd_data->d_dc_du, N*2*N*K*sizeof(T)));",
+            "gpuErrchk(hipMalloc((void**)&hd_data->d_df_du, N*2*N*K*sizeof(T)));",
+            "// and the CPU",
+            "gpuErrchk(hipHostMalloc((void**)&hd_data->h_c, N*K*sizeof(T)));",
+            "gpuErrchk(hipHostMalloc((void**)&hd_data->h_Minv, N*N*K*sizeof(T)));",
+            "gpuErrchk(hipHostMalloc((void**)&hd_data->h_qdd, N*K*sizeof(T)));",
+            "gpuErrchk(hipHostMalloc((void**)&hd_data->h_dc_du, N*2*N*K*sizeof(T)));",
+            "gpuErrchk(hipHostMalloc((void**)&hd_data->h_df_du, N*2*N*K*sizeof(T)));",
+            "return hd_data;",
+        ]
+        self.gen_add_func_doc("Allocated device and host memory for all computations", [], [],
+                              "A pointer to the gridData struct of pointers")
+        self.gen_add_code_lines(["template <typename T, int NUM_TIMESTEPS>", "__host__", "gridData<T> *init_gridData(){"], True)
+        self.gen_add_code_lines(body)
+        self.gen_add_end_function()
+        self.gen_add_func_doc("Allocated device and host memory for all computations", [],
+                              ["Max number of timesteps in the trajectory"], "A pointer to the gridData struct of pointers")
+        self.gen_add_code_lines(["template <typename T>", "__host__", "gridData<T> *init_gridData(int NUM_TIMESTEPS){"], True)
+        self.gen_add_code_lines(body)
+        self.gen_add_end_function()
+
+    def gen_init_close_grid(self):
+        MAX_STREAMS = 3
+        self.gen_add_func_doc("Initializes streams for host functions", [
+            "Nothing to configure for LDS: every kernel needs far less than the 64 KiB default dynamic-LDS limit",
+            "(the reference must raise cudaFuncAttributeMaxDynamicSharedMemorySize here, GRiDCodeGenerator.py:164-179)."],
+            [], "A pointer to the array of streams")
+        self.gen_add_code_lines(["template <typename T>", "__host__", "hipStream_t *init_grid(){"], True)
+        self.gen_add_code_lines([
+            "hipStream_t *streams = (hipStream_t *)malloc(%d*sizeof(hipStream_t));" % MAX_STREAMS,
+            "int priority, minPriority, maxPriority;",
+            "gpuErrchk(hipDeviceGetStreamPriorityRange(&minPriority, &maxPriority));",
+            "for(int i=0; i<%d; i++){" % MAX_STREAMS,
+            "    int adjusted_max = maxPriority - i; priority = adjusted_max > minPriority ? adjusted_max : minPriority;",
+            "    gpuErrchk(hipStreamCreateWithPriority(&(streams[i]),hipStreamNonBlocking,priority));",
+            "}",
+            "return streams;",
+        ])
+        self.gen_add_end_function()
+        self.gen_add_func_doc("Frees the memory used by grid", [
+            "Unlike the reference (GRiDCodeGenerator.py:194-202) this also frees d_XImats, d_topology_helpers and hd_data itself."],
+            ["streams allocated by init_grid", "robotModel allocated by init_robotModel", "data allocated by init_gridData"], None)
+        self.gen_add_code_lines(["template <typename T>", "__host__",
+                                 "void close_grid(hipStream_t *streams, robotModel<T> *d_robotModel, gridData<T> *hd_data){"], True)
+        self.gen_add_code_lines([
+            "if (d_robotModel != nullptr){",
+            "    robotModel<T> h_robotModel; gpuErrchk(hipMemcpy(&h_robotModel,d_robotModel,sizeof(robotModel<T>),hipMemcpyDeviceToHost));",
+            "    gpuErrchk(hipFree(h_robotModel.d_XImats)); if (h_robotModel.d_topology_helpers != nullptr){gpuErrchk(hipFree(h_robotModel.d_topology_helpers));}",
+            "    gpuErrchk(hipFree(d_robotModel));",
+            "}",
+            "if (hd_data != nullptr){",
+            "    gpuErrchk(hipFree(hd_data->d_q_qd_u)); gpuErrchk(hipFree(hd_data->d_q_qd)); gpuErrchk(hipFree(hd_data->d_q));",
+            "    gpuErrchk(hipFree(hd_data->d_c)); gpuErrchk(hipFree(hd_data->d_Minv)); gpuErrchk(hipFree(hd_data->d_qdd));",
+            "    gpuErrchk(hipFree(hd_data->d_dc_du)); gpuErrchk(hipFree(hd_data->d_df_du));",
+            "    gpuErrchk(hipHostFree(hd_data->h_q_qd_u)); gpuErrchk(hipHostFree(hd_data->h_q_qd)); gpuErrchk(hipHostFree(hd_data->h_q));",
+            "    gpuErrchk(hipHostFree(hd_data->h_c)); gpuErrchk(hipHostFree(hd_data->h_Minv)); gpuErrchk(hipHostFree(hd_data->h_qdd));",
+            "    gpuErrchk(hipHostFree(hd_data->h_dc_du)); gpuErrchk(hipHostFree(hd_data->h_df_du));",
+            "    free(hd_data);",
+            "}",
+            "if (streams != nullptr){for(int i=0; i<%d; i++){gpuErrchk(hipStreamDestroy(streams[i]));} free(streams);}" % MAX_STREAMS,
+        ])
+        self.gen_add_end_function()

@@ -1,0 +1,318 @@
+"""Python host side: build the per-robot shared object and drive it through the C ABI (ctypes).
+
+This replaces the reference user's nvcc ``main()`` that includes ``grid.cuh`` (SURVEY.md section
+8(b)): the generated ``grid_<robot>.hip.h`` is compiled together with ``csrc/grid_capi.hip`` into
+``_build/libgrid_<robot>_<precision>.so`` and every call below is one C-ABI entry point declared in
+``include/grid_capi.h``.  There is NO CPU fallback: a missing library raises ``GridLibraryError``.
+
+``GridHandle`` mirrors the reference's host wrappers -- same names, argument meaning and buffer
+layouts (``q_qd_u[K][3n]`` in; ``c``, ``Minv``, ``qdd``, ``dc_du``, ``df_du`` out) -- and adds the
+``*_device`` variants that operate on device pointers (reference mode 2, ``_compute_only``).
+"""
+import ctypes
+import hashlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from .GRiDCodeGenerator import GRiDCodeGenerator
+from .robots import get_robot
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+REPO_DIR = os.path.dirname(PKG_DIR)
+BUILD_DIR = os.path.join(PKG_DIR, "_build")
+CSRC = os.path.join(PKG_DIR, "csrc", "grid_capi.hip")
+INCLUDE_DIR = os.path.join(REPO_DIR, "include")
+ARCH = "gfx950"
+
+ALG_ID, ALG_MINV, ALG_FD, ALG_ID_DU, ALG_FD_DU = range(5)
+ALG_NAMES = {ALG_ID: "inverse_dynamics", ALG_MINV: "direct_minv", ALG_FD: "forward_dynamics",
+             ALG_ID_DU: "inverse_dynamics_gradient", ALG_FD_DU: "forward_dynamics_gradient"}
+
+
+class GridLibraryError(RuntimeError):
+    pass
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def _source_fingerprint(extra=""):
+    h = hashlib.sha256()
+    for root in (os.path.join(PKG_DIR, "emit"), os.path.join(PKG_DIR, "helpers"), os.path.join(PKG_DIR, "algorithms")):
+        for fn in sorted(os.listdir(root)):
+            if fn.endswith(".py"):
+                with open(os.path.join(root, fn), "rb") as fh:
+                    h.update(fh.read())
+    for fn in (os.path.join(PKG_DIR, "GRiDCodeGenerator.py"), os.path.join(PKG_DIR, "robots.py"),
+               os.path.join(PKG_DIR, "robot_model.py"), CSRC, os.path.join(INCLUDE_DIR, "grid_capi.h")):
+        with open(fn, "rb") as fh:
+            h.update(fh.read())
+    h.update(extra.encode())
+    return h.hexdigest()
+
+
+def library_paths(robot_name, precision="fp32"):
+    tag = "%s_%s" % (robot_name, precision)
+    return dict(tag=tag, header=os.path.join(BUILD_DIR, "grid_%s.hip.h" % tag),
+                lib=os.path.join(BUILD_DIR, "libgrid_%s.so" % tag), stamp=os.path.join(BUILD_DIR, "grid_%s.stamp" % tag),
+                log=os.path.join(BUILD_DIR, "grid_%s.build.log" % tag))
+
+
+def generate_header(robot, path, namespace, **gen_kwargs):
+    """Run the generator for ``robot`` and move ``<namespace>.hip.h`` (written to the CWD, as the
+    reference writes grid.cuh to the CWD, GRiDCodeGenerator.py:308) to ``path``."""
+    gen = GRiDCodeGenerator(robot, FILE_NAMESPACE=namespace, **gen_kwargs)
+    cwd = os.getcwd()
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    os.chdir(os.path.dirname(path))
+    try:
+        gen.gen_all_code()
+        os.replace(gen.output_file_name(), path)
+    finally:
+        os.chdir(cwd)
+    return gen
+
+
+def build_library(robot_name, precision="fp32", force=False, verbose=False, extra_flags=(), **gen_kwargs):
+    """Generate + compile the shared object for a built-in robot.  Returns the .so path."""
+    p = library_paths(robot_name, precision)
+    flags = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-shared", "-std=c++17", "-I" + INCLUDE_DIR] + list(extra_flags)
+    fp = _source_fingerprint(repr(sorted(gen_kwargs.items())) + precision + " ".join(flags))
+    if not force and os.path.exists(p["lib"]) and os.path.exists(p["stamp"]):
+        with open(p["stamp"]) as fh:
+            if fh.read().strip() == fp:
+                return p["lib"]
+    os.makedirs(BUILD_DIR, exist_ok=True)
+    ns = "grid_" + robot_name
+    generate_header(get_robot(robot_name), p["header"], ns, precision=precision, **gen_kwargs)
+    cmd = [_hipcc()] + flags + ["-DGRID_HEADER=\"%s\"" % p["header"], "-DGRID_NS=" + ns,
+                                "-DGRID_ROBOT_NAME=\"%s\"" % robot_name, "-Rpass-analysis=kernel-resource-usage",
+                                CSRC, "-o", p["lib"] + ".tmp"]
+    if verbose:
+        print("[grid build]", " ".join(cmd), file=sys.stderr)
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    with open(p["log"], "w") as fh:
+        fh.write(" ".join(cmd) + "\n" + proc.stdout)
+    if proc.returncode != 0:
+        raise GridLibraryError("hipcc failed for %s (see %s):\n%s" % (p["tag"], p["log"], proc.stdout[-4000:]))
+    os.replace(p["lib"] + ".tmp", p["lib"])
+    with open(p["stamp"], "w") as fh:
+        fh.write(fp)
+    return p["lib"]
+
+
+_c_float_p = ctypes.POINTER(ctypes.c_float)
+_c_int_p = ctypes.POINTER(ctypes.c_int)
+_vp = ctypes.c_void_p
+
+# (name, restype, argtypes) -- must list every symbol include/grid_capi.h declares (tests check this)
+CAPI_SIGNATURES = [
+    ("grid_robot_name", ctypes.c_char_p, []),
+    ("grid_num_joints", ctypes.c_int, []),
+    ("grid_constants", ctypes.c_int, [_c_int_p, ctypes.c_int]),
+    ("grid_compute_dtype", ctypes.c_char_p, []),
+    ("grid_last_error", ctypes.c_char_p, []),
+    ("grid_init", ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
+    ("grid_alloc", ctypes.c_int, [_vp, ctypes.c_int]),
+    ("grid_close", ctypes.c_int, [_vp]),
+    ("grid_topology_helpers_count", ctypes.c_int, []),
+    ("grid_read_model", ctypes.c_int, [_vp, _c_float_p, _c_int_p]),
+    ("grid_inverse_dynamics", ctypes.c_int, [_vp, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_float]),
+    ("grid_direct_minv", ctypes.c_int, [_vp, _c_float_p, _c_float_p, ctypes.c_int]),
+    ("grid_forward_dynamics", ctypes.c_int, [_vp, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_float]),
+    ("grid_inverse_dynamics_gradient", ctypes.c_int, [_vp, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_float]),
+    ("grid_forward_dynamics_gradient", ctypes.c_int, [_vp, _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_float]),
+    ("grid_inverse_dynamics_device", ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, _vp]),
+    ("grid_direct_minv_device", ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
+    ("grid_forward_dynamics_device", ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, _vp]),
+    ("grid_inverse_dynamics_gradient_device", ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, _vp]),
+    ("grid_forward_dynamics_gradient_device", ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, _vp]),
+    ("grid_synchronize", ctypes.c_int, [_vp, _vp]),
+    ("grid_time_device", ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_float,
+                                        ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _c_float_p]),
+    ("grid_kernel_attributes", ctypes.c_int, [ctypes.c_int, ctypes.c_int, _c_int_p]),
+]
+
+
+class GridLibrary:
+    """ctypes binding of one ``libgrid_<robot>_<precision>.so``."""
+
+    def __init__(self, robot_name, precision="fp32", path=None):
+        self.robot_name = robot_name
+        self.path = path or library_paths(robot_name, precision)["lib"]
+        if not os.path.exists(self.path):
+            raise GridLibraryError(
+                "HIP library %s is not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is deliberately no CPU fallback)" % self.path)
+        self.lib = ctypes.CDLL(self.path, mode=ctypes.RTLD_LOCAL)
+        for (name, restype, argtypes) in CAPI_SIGNATURES:
+            fn = getattr(self.lib, name)  # AttributeError if the library does not export it
+            fn.restype = restype
+            fn.argtypes = argtypes
+        self.n = int(self.lib.grid_num_joints())
+        consts = (ctypes.c_int * 10)()
+        self.lib.grid_constants(consts, 10)
+        keys = ["NUM_JOINTS", "ID_DYNAMIC_SHARED_MEM_COUNT", "MINV_DYNAMIC_SHARED_MEM_COUNT", "FD_DYNAMIC_SHARED_MEM_COUNT",
+                "ID_DU_DYNAMIC_SHARED_MEM_COUNT", "FD_DU_DYNAMIC_SHARED_MEM_COUNT", "ID_DU_MAX_SHARED_MEM_COUNT",
+                "FD_DU_MAX_SHARED_MEM_COUNT", "SUGGESTED_THREADS", "SUGGESTED_MAX_BLOCKS"]
+        self.constants = dict(zip(keys, list(consts)))
+        self.compute_dtype = self.lib.grid_compute_dtype().decode()
+
+    def last_error(self):
+        return self.lib.grid_last_error().decode(errors="replace")
+
+    def check(self, rc, what):
+        if rc != 0:
+            raise GridLibraryError("%s failed (code %d): %s" % (what, rc, self.last_error()))
+
+    def kernel_attributes(self, alg, variant=0):
+        out = (ctypes.c_int * 4)()
+        self.check(self.lib.grid_kernel_attributes(alg, variant, out), "grid_kernel_attributes")
+        return dict(numRegs=out[0], static_lds_bytes=out[1], scratch_bytes_per_lane=out[2], maxThreadsPerBlock=out[3])
+
+
+def _f32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError("expected shape %s, got %s" % (shape, a.shape))
+    return a
+
+
+def _fp(a):
+    return a.ctypes.data_as(_c_float_p)
+
+
+class GridHandle:
+    """One robot model on one GPU: ``init_robotModel`` + ``init_grid`` (+ ``init_gridData``)."""
+
+    def __init__(self, robot_name, device=0, precision="fp32", max_timesteps=0, library=None):
+        self.L = library or GridLibrary(robot_name, precision)
+        self.n = self.L.n
+        self._h = _vp()
+        self.L.check(self.L.lib.grid_init(int(device), ctypes.byref(self._h)), "grid_init")
+        self.max_timesteps = 0
+        if max_timesteps:
+            self.alloc(max_timesteps)
+
+    # lifecycle ------------------------------------------------------------------------------------
+    def alloc(self, max_timesteps):
+        self.L.check(self.L.lib.grid_alloc(self._h, int(max_timesteps)), "grid_alloc")
+        self.max_timesteps = int(max_timesteps)
+
+    def close(self):
+        if self._h:
+            h, self._h = self._h, _vp()
+            self.L.check(self.L.lib.grid_close(h), "grid_close")
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ensure(self, K):
+        if K > self.max_timesteps:
+            self.alloc(K)
+
+    def read_model(self):
+        XI = np.zeros(72 * self.n, dtype=np.float32)
+        nt = int(self.L.lib.grid_topology_helpers_count())
+        topo = np.zeros(max(nt, 1), dtype=np.int32)
+        self.L.check(self.L.lib.grid_read_model(self._h, _fp(XI), topo.ctypes.data_as(_c_int_p)), "grid_read_model")
+        return XI, topo[:nt]
+
+    # host-buffer calls (reference host wrappers, mode 0) -----------------------------------------------
+    def inverse_dynamics(self, q_qd_u, qdd=None, gravity=9.81):
+        q_qd_u = _f32(q_qd_u); K = q_qd_u.shape[0]; n = self.n
+        _f32(q_qd_u, (K, 3 * n)); self._ensure(K)
+        qdd_p = _fp(_f32(qdd, (K, n))) if qdd is not None else None
+        out = np.empty((K, n), dtype=np.float32)
+        self.L.check(self.L.lib.grid_inverse_dynamics(self._h, _fp(q_qd_u), qdd_p, _fp(out), K, gravity), "grid_inverse_dynamics")
+        return out
+
+    def direct_minv(self, q_qd_u):
+        q_qd_u = _f32(q_qd_u); K = q_qd_u.shape[0]; n = self.n
+        _f32(q_qd_u, (K, 3 * n)); self._ensure(K)
+        out = np.empty((K, n * n), dtype=np.float32)
+        self.L.check(self.L.lib.grid_direct_minv(self._h, _fp(q_qd_u), _fp(out), K), "grid_direct_minv")
+        return out
+
+    def forward_dynamics(self, q_qd_u, gravity=9.81):
+        q_qd_u = _f32(q_qd_u); K = q_qd_u.shape[0]; n = self.n
+        _f32(q_qd_u, (K, 3 * n)); self._ensure(K)
+        out = np.empty((K, n), dtype=np.float32)
+        self.L.check(self.L.lib.grid_forward_dynamics(self._h, _fp(q_qd_u), _fp(out), K, gravity), "grid_forward_dynamics")
+        return out
+
+    def inverse_dynamics_gradient(self, q_qd_u, qdd=None, gravity=9.81):
+        q_qd_u = _f32(q_qd_u); K = q_qd_u.shape[0]; n = self.n
+        _f32(q_qd_u, (K, 3 * n)); self._ensure(K)
+        qdd_a = _f32(qdd, (K, n)) if qdd is not None else None
+        out = np.empty((K, 2 * n * n), dtype=np.float32)
+        self.L.check(self.L.lib.grid_inverse_dynamics_gradient(self._h, _fp(q_qd_u), _fp(qdd_a) if qdd_a is not None else None,
+                                                               _fp(out), K, gravity), "grid_inverse_dynamics_gradient")
+        return out
+
+    def forward_dynamics_gradient(self, q_qd_u, qdd=None, Minv=None, gravity=9.81):
+        q_qd_u = _f32(q_qd_u); K = q_qd_u.shape[0]; n = self.n
+        _f32(q_qd_u, (K, 3 * n)); self._ensure(K)
+        qdd_a = _f32(qdd, (K, n)) if qdd is not None else None
+        Minv_a = _f32(Minv, (K, n * n)) if Minv is not None else None
+        out = np.empty((K, 2 * n * n), dtype=np.float32)
+        self.L.check(self.L.lib.grid_forward_dynamics_gradient(
+            self._h, _fp(q_qd_u), _fp(qdd_a) if qdd_a is not None else None, _fp(Minv_a) if Minv_a is not None else None,
+            _fp(out), K, gravity), "grid_forward_dynamics_gradient")
+        return out
+
+    # device-pointer calls (reference mode 2); pointers are ints (e.g. torch.Tensor.data_ptr()) --------------
+    def inverse_dynamics_device(self, d_c, d_q_qd, stride, K, d_qdd=None, gravity=9.81, blocks=0, threads=0, stream=None):
+        self.L.check(self.L.lib.grid_inverse_dynamics_device(self._h, d_c, d_q_qd, stride, d_qdd, K, gravity, blocks, threads, stream),
+                     "grid_inverse_dynamics_device")
+
+    def direct_minv_device(self, d_Minv, d_q, stride, K, blocks=0, threads=0, stream=None):
+        self.L.check(self.L.lib.grid_direct_minv_device(self._h, d_Minv, d_q, stride, K, blocks, threads, stream), "grid_direct_minv_device")
+
+    def forward_dynamics_device(self, d_qdd, d_q_qd_u, stride, K, gravity=9.81, blocks=0, threads=0, stream=None):
+        self.L.check(self.L.lib.grid_forward_dynamics_device(self._h, d_qdd, d_q_qd_u, stride, K, gravity, blocks, threads, stream),
+                     "grid_forward_dynamics_device")
+
+    def inverse_dynamics_gradient_device(self, d_dc_du, d_q_qd, stride, K, d_qdd=None, gravity=9.81, blocks=0, threads=0, stream=None):
+        self.L.check(self.L.lib.grid_inverse_dynamics_gradient_device(self._h, d_dc_du, d_q_qd, stride, d_qdd, K, gravity, blocks, threads, stream),
+                     "grid_inverse_dynamics_gradient_device")
+
+    def forward_dynamics_gradient_device(self, d_df_du, d_q_qd_u, stride, K, d_qdd=None, d_Minv=None, gravity=9.81,
+                                         blocks=0, threads=0, stream=None):
+        self.L.check(self.L.lib.grid_forward_dynamics_gradient_device(self._h, d_df_du, d_q_qd_u, stride, d_qdd, d_Minv, K, gravity,
+                                                                      blocks, threads, stream), "grid_forward_dynamics_gradient_device")
+
+    def synchronize(self, stream=None):
+        self.L.check(self.L.lib.grid_synchronize(self._h, stream), "grid_synchronize")
+
+    def time_device(self, alg, d_out, d_in, stride, K, d_qdd=None, d_Minv=None, gravity=9.81, blocks=0, threads=0, stream=None, reps=20):
+        ms = ctypes.c_float(0.0)
+        self.L.check(self.L.lib.grid_time_device(self._h, alg, d_out, d_in, stride, d_qdd, d_Minv, K, gravity, blocks, threads, stream,
+                                                 reps, ctypes.byref(ms)), "grid_time_device")
+        return float(ms.value)
+
+
+def output_size(alg, n):
+    return {ALG_ID: n, ALG_MINV: n * n, ALG_FD: n, ALG_ID_DU: 2 * n * n, ALG_FD_DU: 2 * n * n}[alg]
+
+
+def algorithmic_bytes(alg, n):
+    """compulsory input + output bytes per evaluation (fp32)."""
+    return 4 * {ALG_ID: 2 * n + n, ALG_MINV: n + n * n, ALG_FD: 3 * n + n, ALG_ID_DU: 2 * n + 2 * n * n,
+                ALG_FD_DU: 3 * n + 2 * n * n}[alg]

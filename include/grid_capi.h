@@ -1,0 +1,92 @@
+/*
+ * grid_capi.h -- C ABI of the MI355X-native GRiD library (one shared object per robot model).
+ *
+ * The reference (robot-acceleration/GRiDCodeGenerator) has NO C ABI: its product is a CUDA header of
+ * C++ templates that the user's own nvcc main() includes.  This shim is the
+ * FFI a non-C++ host (Python ctypes here) binds instead; every entry point names the emitted
+ * reference interface it stands for.  Plain pointers and sizes only; all functions return 0 on
+ * success or a hipError_t-style non-zero code (never exit()), with text from grid_last_error().
+ *
+ * Buffer layouts are the reference's gridData<T> layouts, T = float (GRiDCodeGenerator.py:92-137):
+ *   q_qd_u[K][3n] = [q | qd | u]    q_qd[K][2n]    q[K][n]    qdd[K][n]
+ *   c[K][n]   Minv[K][n*n] column-major, upper triangle (lower half 0)   qdd[K][n]
+ *   dc_du[K][2*n*n], df_du[K][2*n*n]: n x 2n column-major = [d/dq | d/dqd]
+ */
+#ifndef GRID_CAPI_H
+#define GRID_CAPI_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct grid_handle grid_handle;
+
+/* algorithm ids (order of the reference's <FUNC_CODE> list, GRiDCodeGenerator.py:279) */
+enum { GRID_ALG_ID = 0, GRID_ALG_MINV = 1, GRID_ALG_FD = 2, GRID_ALG_ID_DU = 3, GRID_ALG_FD_DU = 4 };
+
+/* ---- model / build constants (reference: the `const int` block, GRiDCodeGenerator.py:75-83) ---- */
+const char *grid_robot_name(void);
+int grid_num_joints(void);                                   /* NUM_JOINTS */
+/* out[0..9] = NUM_JOINTS, ID/MINV/FD/ID_DU/FD_DU_DYNAMIC_SHARED_MEM_COUNT, ID_DU/FD_DU_MAX_SHARED_MEM_COUNT,
+ *             SUGGESTED_THREADS, SUGGESTED_MAX_BLOCKS */
+int grid_constants(int *out, int count);
+const char *grid_compute_dtype(void);                        /* "f32" or "f64": arithmetic type for T=float */
+const char *grid_last_error(void);
+
+/* ---- lifecycle ---- */
+/* init_robotModel<T>() + init_grid<T>() on `device` (GRiDCodeGenerator.py:155-189, helpers/_topology_helpers.py:365-380) */
+int grid_init(int device, grid_handle **out);
+/* init_gridData<T>(max_timesteps) (GRiDCodeGenerator.py:116-153); needed only by the host-buffer calls */
+int grid_alloc(grid_handle *h, int max_timesteps);
+/* close_grid<T>(streams, d_robotModel, hd_data) (GRiDCodeGenerator.py:191-203) */
+int grid_close(grid_handle *h);
+/* copy back what init_robotModel uploaded: h_XImats[72n], h_topology[grid_topology_helpers_count()] */
+int grid_topology_helpers_count(void);
+int grid_read_model(grid_handle *h, float *h_XImats, int *h_topology);
+
+/* ---- host-buffer calls = the reference's host wrappers, mode 0 (H2D, kernel, D2H, synchronous) ----
+ * inverse_dynamics<T,USE_QDD_FLAG>            algorithms/_inverse_dynamics.py:423-495   (h_qdd may be NULL)
+ * direct_minv<T>                              algorithms/_direct_minv.py:456-517
+ * forward_dynamics<T>                         algorithms/_forward_dynamics.py:196-252
+ * inverse_dynamics_gradient<T,USE_QDD_FLAG>   algorithms/_inverse_dynamics_gradient.py:762-834
+ * forward_dynamics_gradient<T,USE_QDD_MINV>   algorithms/_forward_dynamics_gradient.py:179-242 (h_qdd and h_Minv both NULL or both set)
+ */
+int grid_inverse_dynamics(grid_handle *h, const float *h_q_qd_u, const float *h_qdd, float *h_c, int num_timesteps, float gravity);
+int grid_direct_minv(grid_handle *h, const float *h_q_qd_u, float *h_Minv, int num_timesteps);
+int grid_forward_dynamics(grid_handle *h, const float *h_q_qd_u, float *h_qdd, int num_timesteps, float gravity);
+int grid_inverse_dynamics_gradient(grid_handle *h, const float *h_q_qd_u, const float *h_qdd, float *h_dc_du, int num_timesteps, float gravity);
+int grid_forward_dynamics_gradient(grid_handle *h, const float *h_q_qd_u, const float *h_qdd, const float *h_Minv, float *h_df_du,
+                                   int num_timesteps, float gravity);
+
+/* ---- device-pointer calls = the kernels themselves (reference mode 2, `_compute_only`), asynchronous ----
+ * Arguments mirror the __global__ signatures: _inverse_dynamics.py:365-369, _direct_minv.py:414, _forward_dynamics.py:151-152,
+ * _inverse_dynamics_gradient.py:703-707, _forward_dynamics_gradient.py:117-125.
+ * blocks/threads <= 0 selects the suggested launch shape; stream == NULL uses the handle's first stream.
+ */
+int grid_inverse_dynamics_device(grid_handle *h, float *d_c, const float *d_q_qd, int stride_q_qd, const float *d_qdd,
+                                 int num_timesteps, float gravity, int blocks, int threads, void *stream);
+int grid_direct_minv_device(grid_handle *h, float *d_Minv, const float *d_q, int stride_q,
+                            int num_timesteps, int blocks, int threads, void *stream);
+int grid_forward_dynamics_device(grid_handle *h, float *d_qdd, const float *d_q_qd_u, int stride_q_qd_u,
+                                 int num_timesteps, float gravity, int blocks, int threads, void *stream);
+int grid_inverse_dynamics_gradient_device(grid_handle *h, float *d_dc_du, const float *d_q_qd, int stride_q_qd, const float *d_qdd,
+                                          int num_timesteps, float gravity, int blocks, int threads, void *stream);
+int grid_forward_dynamics_gradient_device(grid_handle *h, float *d_df_du, const float *d_q_qd_u, int stride_q_qd_u,
+                                          const float *d_qdd, const float *d_Minv,
+                                          int num_timesteps, float gravity, int blocks, int threads, void *stream);
+int grid_synchronize(grid_handle *h, void *stream);
+
+/* ---- measurement ----
+ * `reps` back-to-back launches of algorithm `alg` on `stream`, bracketed by hipEvents recorded on that same stream;
+ * *ms_per_launch = elapsed / reps.  (Replaces the reference's `_single_timing` clock_gettime twins,
+ * algorithms/_forward_dynamics_gradient.py:229-241, which time block latency rather than throughput.) */
+int grid_time_device(grid_handle *h, int alg, float *d_out, const float *d_in, int stride, const float *d_qdd, const float *d_Minv,
+                     int num_timesteps, float gravity, int blocks, int threads, void *stream, int reps, float *ms_per_launch);
+/* hipFuncGetAttributes of the kernel for `alg` (variant: 0 default inputs, 1 with qdd / qdd+Minv):
+ * out[0]=numRegs out[1]=static LDS bytes out[2]=scratch (local) bytes per lane out[3]=maxThreadsPerBlock */
+int grid_kernel_attributes(int alg, int variant, int *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRID_CAPI_H */
