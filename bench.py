@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Headline benchmark: forward-dynamics-gradient evaluations per second, iiwa-7, batch 16384 per GPU.
+
+Contract (task statement): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 it is launched
+by ``python -m torch.distributed.run --nproc-per-node N ...`` with one rank per GPU.  One "step" is one
+pass of the hot path -- ``forward_dynamics_gradient_kernel`` over one batch of synthetic (q, qd, u)
+already resident in HBM -- launched through the C ABI on torch's current stream.  W untimed warm-up
+steps, then exactly K steps bracketed by barrier + torch.cuda.synchronize(); the time is the MAX over
+ranks; rank 0 prints ONE JSON line.
+
+Sharding: the batch dimension is embarrassingly parallel, every rank owns its own contiguous slice
+(weak scaling: 16384 configurations per GPU), there is NO collective on the data path; torch.distributed
+(RCCL) is used only for the barrier and the max-over-ranks of the elapsed time.
+
+roofline: algorithmic bytes per launch = 4*(3n + 2n^2) * batch, divided by the
+kernel's average launch duration measured with HIP events on the launch stream (grid_time_device).
+cpu_baseline: the numpy oracle (oracle/rbd_oracle.py, a float64 port of the reference algorithm) timed on
+this box's host cores, rank 0 at N=1 only, on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+GRAVITY = 9.81
+
+
+def make_inputs(n, K, seed):
+    """q ~ U(-pi, pi), qd ~ U(-1, 1), u ~ U(-1, 1), float64 draw cast to fp32."""
+    rng = np.random.default_rng(seed)
+    q = rng.uniform(-np.pi, np.pi, (K, n)).astype(np.float32)
+    qd = rng.uniform(-1.0, 1.0, (K, n)).astype(np.float32)
+    u = rng.uniform(-1.0, 1.0, (K, n)).astype(np.float32)
+    return q, qd, u
+
+
+def cpu_baseline(robot_name, q, qd, u, passes):
+    """numpy float64 oracle on the host cores (single process => cores = 1)."""
+    from gridcodegenerator_amd.robots import get_robot
+    from oracle import rbd_oracle as O
+    T = O.RobotTables(get_robot(robot_name))
+    q64, qd64, u64 = (a.astype(np.float64) for a in (q, qd, u))
+    O.fd_grad(T, q64[:64], qd64[:64], u64[:64])  # warm numpy
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        O.fd_grad(T, q64, qd64, u64)
+    dt = time.perf_counter() - t0
+    return dict(value=passes * q.shape[0] / dt, unit="evals/s", cores=1, kind="port",
+                sample="%d pass(es) of oracle.fd_grad (numpy float64, batch-vectorised) over the same %d-configuration batch, %.1f s"
+                       % (passes, q.shape[0], dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--robot", default="iiwa7")
+    ap.add_argument("--batch", type=int, default=16384, help="configurations per GPU")
+    ap.add_argument("--precision", default="fp32")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-passes", type=int, default=2)
+    ap.add_argument("--blocks", type=int, default=0)
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--all-kernels", action="store_true", help="also time the other four kernels (reported under 'kernels')")
+    args = ap.parse_args()
+
+    import torch
+    from gridcodegenerator_amd import host
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    host.build_library(args.robot, args.precision)
+    h = host.GridHandle(args.robot, device=local_rank, precision=args.precision)
+    n, K = h.n, args.batch
+    # every rank owns an independent slice of the global batch (seed differs per rank)
+    q, qd, u = make_inputs(n, K, 3 + rank)
+    x = np.ascontiguousarray(np.concatenate([q, qd, u], axis=1))
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.empty((K, 2 * n * n), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        h.forward_dynamics_gradient_device(d_out.data_ptr(), d_in.data_ptr(), 3 * n, K, gravity=GRAVITY,
+                                           blocks=args.blocks, threads=args.threads, stream=stream)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # in-stream kernel duration (HIP events recorded on the launch stream by the C ABI)
+    kern_ms = h.time_device(host.ALG_FD_DU, d_out.data_ptr(), d_in.data_ptr(), 3 * n, K, gravity=GRAVITY,
+                            blocks=args.blocks, threads=args.threads, stream=stream, reps=max(20, min(args.steps, 200)))
+    finite = bool(torch.isfinite(d_out).all().item())
+
+    if rank == 0:
+        total_evals = float(world) * K * args.steps
+        alg_bytes = host.algorithmic_bytes(host.ALG_FD_DU, n) * K
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        attrs = h.L.kernel_attributes(host.ALG_FD_DU)
+        out = {
+            "metric": "FD-gradient evals/sec (iiwa-7, batch=16k) + achieved HBM GB/s vs peak" if args.robot == "iiwa7" and K == 16384
+                      else "FD-gradient evals/sec (%s, batch=%d)" % (args.robot, K),
+            "value": total_evals / elapsed, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": h.L.compute_dtype, "data": "synthetic",
+            "config": {"workload": "%s forward_dynamics_gradient_kernel, batch %d per GPU, fp32 I/O, device-resident (reference _compute_only)"
+                                   % (args.robot, K),
+                       "robot": args.robot, "num_joints": n, "batch_per_gpu": K, "global_batch": K * world,
+                       "parallelism": "batch-sharded x%d, independent streams, no collective on the data path" % world,
+                       "launch": {"blocks": args.blocks or "suggested", "threads": args.threads or h.L.constants["SUGGESTED_THREADS"]},
+                       "kernel": {"vgprs": attrs["numRegs"], "scratch_bytes_per_lane": attrs["scratch_bytes_per_lane"]},
+                       "outputs_finite": finite},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": None, "kernel": "forward_dynamics_gradient_kernel", "kernel_avg_us": 1e3 * kern_ms,
+                         "algorithmic_bytes_per_eval": host.algorithmic_bytes(host.ALG_FD_DU, n),
+                         "kernel_evals_per_s": K / (kern_ms * 1e-3)},
+        }
+        if args.all_kernels:
+            kern = {}
+            bufs = {a: torch.empty((K, host.output_size(a, n)), dtype=torch.float32, device="cuda") for a in range(5)}
+            for a in range(5):
+                ms = h.time_device(a, bufs[a].data_ptr(), d_in.data_ptr(), 3 * n, K, gravity=GRAVITY, stream=stream, reps=50)
+                by = host.algorithmic_bytes(a, n) * K
+                kern[host.ALG_NAMES[a]] = {"avg_us": 1e3 * ms, "evals_per_s": K / (ms * 1e-3), "alg_GBps": by / (ms * 1e-3) / 1e9}
+            out["kernels"] = kern
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.robot, q, qd, u, args.cpu_passes)
+        print(json.dumps(out), flush=True)
+    h.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -16,6 +16,13 @@
 namespace G = GRID_NS;
 typedef float T;
 
+#ifdef GRID_EXTERN_KERNELS
+// kernels are instantiated one per translation unit (grid_kernel_inst.hip) and linked in
+#include "grid_kernel_list.inc"
+GRID_KERNEL_0(extern template) GRID_KERNEL_1(extern template) GRID_KERNEL_2(extern template) GRID_KERNEL_3(extern template)
+GRID_KERNEL_4(extern template) GRID_KERNEL_5(extern template) GRID_KERNEL_6(extern template) GRID_KERNEL_7(extern template)
+#endif
+
 struct grid_handle {
     int device;
     G::robotModel<T> *d_robotModel;

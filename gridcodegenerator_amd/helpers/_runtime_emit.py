@@ -203,10 +203,15 @@ class RuntimeEmitMixin:
             "                                               const int NUM_TIMESTEPS, T *s_wave, const bool staged){",
             "    if (staged){",
             "        const int nvalid = min(GRID_WAVE_SIZE, NUM_TIMESTEPS - k0);",
-            "        #pragma unroll",
+            "        const T *src = d_src + (size_t)k0*stride;",
+            "        // rolled on purpose: fully unrolled, the per-t (cfg, i) address pairs are loop invariant and get",
+            "        // hoisted out of the tile loop, pinning N extra registers across the whole straight-line core",
+            "        #pragma unroll 4",
             "        for (int t = 0; t < N; t++){",
             "            const int f = t*GRID_WAVE_SIZE + lane; const int cfg = f / N; const int i = f - cfg*N;",
-            "            s_wave[cfg*NPAD + i] = (cfg < nvalid) ? d_src[(size_t)(k0 + cfg)*stride + i] : static_cast<T>(0);",
+            "            T v = static_cast<T>(0);",
+            "            if (cfg < nvalid){v = src[(size_t)cfg*stride + i];}",
+            "            s_wave[cfg*NPAD + i] = v;",
             "        }",
             "        grid_wave_sync();",
             "        #pragma unroll",
@@ -231,10 +236,11 @@ class RuntimeEmitMixin:
             "        const int base = chunk*CH; const int len = (N_OUT - base < CH) ? (N_OUT - base) : CH;",
             "        const int nvalid = min(GRID_WAVE_SIZE, NUM_TIMESTEPS - k0);",
             "        grid_wave_sync();",
-            "        #pragma unroll",
+            "        T *dst = d_dst + (size_t)k0*N_OUT + base;",
+            "        #pragma unroll 4",
             "        for (int t = 0; t < len; t++){",
             "            const int f = t*GRID_WAVE_SIZE + lane; const int cfg = f / len; const int i = f - cfg*len;",
-            "            if (cfg < nvalid){d_dst[(size_t)(k0 + cfg)*N_OUT + base + i] = s_wave[cfg*CHPAD + i];}",
+            "            if (cfg < nvalid){dst[(size_t)cfg*N_OUT + i] = s_wave[cfg*CHPAD + i];}",
             "        }",
             "        grid_wave_sync();",
             "    }",

@@ -14,6 +14,7 @@ import hashlib
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -24,6 +25,8 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
 BUILD_DIR = os.path.join(PKG_DIR, "_build")
 CSRC = os.path.join(PKG_DIR, "csrc", "grid_capi.hip")
+KERNEL_INST_SRC = os.path.join(PKG_DIR, "csrc", "grid_kernel_inst.hip")
+NUM_KERNEL_INSTANCES = 8
 INCLUDE_DIR = os.path.join(REPO_DIR, "include")
 ARCH = "gfx950"
 
@@ -51,7 +54,8 @@ def _source_fingerprint(extra=""):
                 with open(os.path.join(root, fn), "rb") as fh:
                     h.update(fh.read())
     for fn in (os.path.join(PKG_DIR, "GRiDCodeGenerator.py"), os.path.join(PKG_DIR, "robots.py"),
-               os.path.join(PKG_DIR, "robot_model.py"), CSRC, os.path.join(INCLUDE_DIR, "grid_capi.h")):
+               os.path.join(PKG_DIR, "robot_model.py"), CSRC, KERNEL_INST_SRC,
+               os.path.join(PKG_DIR, "csrc", "grid_kernel_list.inc"), os.path.join(INCLUDE_DIR, "grid_capi.h")):
         with open(fn, "rb") as fh:
             h.update(fh.read())
     h.update(extra.encode())
@@ -92,16 +96,38 @@ def build_library(robot_name, precision="fp32", force=False, verbose=False, extr
     os.makedirs(BUILD_DIR, exist_ok=True)
     ns = "grid_" + robot_name
     generate_header(get_robot(robot_name), p["header"], ns, precision=precision, **gen_kwargs)
-    cmd = [_hipcc()] + flags + ["-DGRID_HEADER=\"%s\"" % p["header"], "-DGRID_NS=" + ns,
-                                "-DGRID_ROBOT_NAME=\"%s\"" % robot_name, "-Rpass-analysis=kernel-resource-usage",
-                                CSRC, "-o", p["lib"] + ".tmp"]
-    if verbose:
-        print("[grid build]", " ".join(cmd), file=sys.stderr)
-    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    # one translation unit per kernel + the C-ABI unit, compiled in parallel, then linked
+    common = [_hipcc()] + [f for f in flags if f != "-shared"] + [
+        "-c", "-DGRID_HEADER=\"%s\"" % p["header"], "-DGRID_NS=" + ns, "-DGRID_ROBOT_NAME=\"%s\"" % robot_name,
+        "-Rpass-analysis=kernel-resource-usage"]
+    objdir = os.path.join(BUILD_DIR, "obj_" + p["tag"])
+    os.makedirs(objdir, exist_ok=True)
+    jobs = [("capi", common + ["-DGRID_EXTERN_KERNELS", CSRC, "-o", os.path.join(objdir, "capi.o")])]
+    for k in range(NUM_KERNEL_INSTANCES):
+        jobs.append(("kernel%d" % k, common + ["-DGRID_INST=%d" % k, KERNEL_INST_SRC, "-o", os.path.join(objdir, "kernel%d.o" % k)]))
+
+    def run(job):
+        name, cmd = job
+        if verbose:
+            print("[grid build] %s: %s" % (p["tag"], name), file=sys.stderr)
+        proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        return name, cmd, proc.returncode, proc.stdout
+
+    workers = max(1, min(len(jobs), int(os.environ.get("GRID_BUILD_JOBS", os.cpu_count() or 4))))
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        results = list(pool.map(run, jobs))
     with open(p["log"], "w") as fh:
-        fh.write(" ".join(cmd) + "\n" + proc.stdout)
+        for (name, cmd, rc, out) in results:
+            fh.write("### %s (rc=%d)\n%s\n%s\n" % (name, rc, " ".join(cmd), out))
+    for (name, cmd, rc, out) in results:
+        if rc != 0:
+            raise GridLibraryError("hipcc failed for %s/%s (see %s):\n%s" % (p["tag"], name, p["log"], out[-4000:]))
+    link = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC"] + [j[1][-1] for j in jobs] + ["-o", p["lib"] + ".tmp"]
+    proc = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    with open(p["log"], "a") as fh:
+        fh.write("### link (rc=%d)\n%s\n%s\n" % (proc.returncode, " ".join(link), proc.stdout))
     if proc.returncode != 0:
-        raise GridLibraryError("hipcc failed for %s (see %s):\n%s" % (p["tag"], p["log"], proc.stdout[-4000:]))
+        raise GridLibraryError("link failed for %s (see %s):\n%s" % (p["tag"], p["log"], proc.stdout[-4000:]))
     os.replace(p["lib"] + ".tmp", p["lib"])
     with open(p["stamp"], "w") as fh:
         fh.write(fp)

@@ -1,0 +1,55 @@
+// TEST INFRASTRUCTURE: compiles the *generated header* for the HOST (hipcc --offload-host-only) and
+// runs the emitted _device / _inner functions on the CPU, one configuration at a time, so the emitted
+// C++ text itself (not just the tracer IR) is checked against the oracle without a GPU.
+// Never part of the product path.
+#include GRID_HEADER
+namespace G = GRID_NS;
+
+template <typename C>
+static void fd_grad(const float *x, float *out, int K, float g) {
+    const int n = G::NUM_JOINTS;
+    for (int k = 0; k < K; k++) {
+        const float *r = x + (size_t)k * 3 * n;
+        G::forward_dynamics_gradient_device<float, C>(out + (size_t)k * 2 * n * n, r, r + n, r + 2 * n, nullptr, g);
+    }
+}
+
+extern "C" {
+int hh_num_joints() { return G::NUM_JOINTS; }
+void hh_fd_grad_f32(const float *x, float *out, int K, float g) { fd_grad<float>(x, out, K, g); }
+void hh_fd_grad_f64(const float *x, float *out, int K, float g) { fd_grad<double>(x, out, K, g); }
+void hh_id(const float *x, const float *qdd, float *out, int K, float g) {
+    const int n = G::NUM_JOINTS;
+    for (int k = 0; k < K; k++) {
+        const float *r = x + (size_t)k * 3 * n;
+        if (qdd) G::inverse_dynamics_device<float>(out + (size_t)k * n, r, r + n, qdd + (size_t)k * n, nullptr, g);
+        else     G::inverse_dynamics_device<float>(out + (size_t)k * n, r, r + n, nullptr, g);
+    }
+}
+void hh_minv(const float *x, float *out, int K) {
+    const int n = G::NUM_JOINTS;
+    for (int k = 0; k < K; k++) G::direct_minv_device<float>(out + (size_t)k * n * n, x + (size_t)k * 3 * n, nullptr);
+}
+void hh_fd(const float *x, float *out, int K, float g) {
+    const int n = G::NUM_JOINTS;
+    for (int k = 0; k < K; k++) { const float *r = x + (size_t)k * 3 * n; G::forward_dynamics_device<float>(out + (size_t)k * n, r, r + n, r + 2 * n, nullptr, g); }
+}
+// the pointer-style _inner tier chained exactly as the reference chains it inside its fused kernel
+// (algorithms/_forward_dynamics_gradient.py:15-25): load_update_XImats_helpers -> direct_minv_inner ->
+// inverse_dynamics_inner (qdd = 0) -> forward_dynamics_finish -> inverse_dynamics_inner_vaf -> inverse_dynamics_gradient_inner
+void hh_inner_chain(const float *x, float *qdd_out, float *dc_du_out, int K, float g) {
+    const int n = G::NUM_JOINTS;
+    float *XI = new float[G::XIMATS_LANE_COUNT], *Minv = new float[n * n], *c = new float[n], *vaf = new float[18 * n];
+    for (int k = 0; k < K; k++) {
+        const float *q = x + (size_t)k * 3 * n, *qd = q + n, *u = q + 2 * n;
+        float *qdd = qdd_out + (size_t)k * n;
+        G::load_update_XImats_helpers<float>(XI, q, nullptr, nullptr);
+        G::direct_minv_inner<float>(Minv, q, XI, nullptr);
+        G::inverse_dynamics_inner<float>(c, vaf, q, qd, XI, nullptr, g);
+        G::forward_dynamics_finish<float>(qdd, u, c, Minv);
+        G::inverse_dynamics_inner_vaf<float>(vaf, q, qd, qdd, XI, nullptr, g);
+        G::inverse_dynamics_gradient_inner<float>(dc_du_out + (size_t)k * 2 * n * n, q, qd, vaf, XI, nullptr, g);
+    }
+    delete[] XI; delete[] Minv; delete[] c; delete[] vaf;
+}
+}

@@ -1,0 +1,111 @@
+"""Drop-in boundary of the generator facade (reference GRiDCodeGenerator.py:37, :241-310)."""
+import os
+import re
+
+import pytest
+
+from gridcodegenerator_amd import GRiDCodeGenerator
+
+PUBLIC_FUNCTIONS = [
+    "init_robotModel", "init_grid", "init_gridData", "close_grid", "init_XImats", "init_topology_helpers",
+    "load_update_XImats_helpers",
+    "inverse_dynamics_inner", "inverse_dynamics_inner_vaf", "inverse_dynamics_device", "inverse_dynamics_vaf_device",
+    "inverse_dynamics_kernel", "inverse_dynamics", "inverse_dynamics_compute_only",
+    "direct_minv_inner", "direct_minv_device", "direct_minv_kernel", "direct_minv", "direct_minv_compute_only",
+    "forward_dynamics_finish", "forward_dynamics_inner", "forward_dynamics_device", "forward_dynamics_kernel",
+    "forward_dynamics", "forward_dynamics_compute_only",
+    "inverse_dynamics_gradient_inner", "inverse_dynamics_gradient_device", "inverse_dynamics_gradient_kernel",
+    "inverse_dynamics_gradient", "inverse_dynamics_gradient_compute_only",
+    "forward_dynamics_gradient_device", "forward_dynamics_gradient_kernel", "forward_dynamics_gradient",
+    "forward_dynamics_gradient_compute_only",
+]
+CONSTANTS = ["NUM_JOINTS", "ID_DYNAMIC_SHARED_MEM_COUNT", "MINV_DYNAMIC_SHARED_MEM_COUNT", "FD_DYNAMIC_SHARED_MEM_COUNT",
+             "ID_DU_DYNAMIC_SHARED_MEM_COUNT", "FD_DU_DYNAMIC_SHARED_MEM_COUNT", "ID_DU_MAX_SHARED_MEM_COUNT",
+             "FD_DU_MAX_SHARED_MEM_COUNT", "SUGGESTED_THREADS"]
+
+
+@pytest.fixture(scope="module")
+def generated(tmp_path_factory, robots):
+    d = tmp_path_factory.mktemp("gen")
+    cwd = os.getcwd()
+    os.chdir(d)
+    try:
+        gen = GRiDCodeGenerator(robots("iiwa7"), DEBUG_MODE=False)   # README usage: GRiDCodeGenerator(robot, DEBUG_MODE=False)
+        ret = gen.gen_all_code()
+    finally:
+        os.chdir(cwd)
+    return d, gen, ret
+
+
+def test_writes_header_into_cwd(generated):
+    d, gen, ret = generated
+    assert ret is None
+    path = os.path.join(d, "grid.hip.h")      # default FILE_NAMESPACE="grid" (reference writes grid.cuh)
+    assert os.path.exists(path)
+    with open(path) as fh:
+        assert fh.read() == gen.code_str
+
+
+def test_emitted_api_surface(generated):
+    code = generated[1].code_str
+    assert "namespace grid {" in code
+    for name in PUBLIC_FUNCTIONS:
+        assert re.search(r"\b%s\(" % name, code), name
+    for const in CONSTANTS:
+        assert re.search(r"const int %s = \d+;" % const, code), const
+    assert "struct robotModel" in code and "struct gridData" in code
+    for field in ("d_q_qd_u", "d_q_qd", "d_q", "h_q_qd_u", "d_c", "d_Minv", "d_qdd", "d_dc_du", "d_df_du", "h_df_du"):
+        assert re.search(r"T \*%s;" % field, code), field
+
+
+def test_kernel_signatures_match_reference(generated):
+    code = generated[1].code_str
+    sigs = [
+        "void inverse_dynamics_kernel(T *d_c, const T *d_q_qd, const int stride_q_qd, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS)",
+        "void inverse_dynamics_kernel(T *d_c, const T *d_q_qd, const int stride_q_qd, const T *d_qdd, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS)",
+        "void direct_minv_kernel(T *d_Minv, const T *d_q, const int stride_q, const robotModel<T> *d_robotModel, const int NUM_TIMESTEPS)",
+        "void forward_dynamics_kernel(T *d_qdd, const T *d_q_qd_u, const int stride_q_qd_u, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS)",
+        "void inverse_dynamics_gradient_kernel(T *d_dc_du, const T *d_q_qd, const int stride_q_qd, const T *d_qdd, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS)",
+        "void forward_dynamics_gradient_kernel(T *d_df_du, const T *d_q_qd_u, const int stride_q_qd_u, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS)",
+        "void forward_dynamics_gradient_kernel(T *d_df_du, const T *d_q_qd, const int stride_q_qd, const T *d_qdd, const T *d_Minv, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS)",
+        "void forward_dynamics_finish(T *s_qdd, const T *s_u, const T *s_c, const T *s_Minv)",
+        "void forward_dynamics_gradient_device(T *s_df_du, const T *s_q, const T *s_qd, const T *s_u, const robotModel<T> *d_robotModel, const T gravity)",
+    ]
+    for s in sigs:
+        assert s in code, s
+
+
+def test_no_cuda_or_compat_layers(generated):
+    code = generated[1].code_str
+    code_only = re.sub(r"/\*.*?\*/", "", code, flags=re.S)
+    code_only = re.sub(r"//[^\n]*", "", code_only)
+    for banned in ("cuda", "__syncthreads", "atomicAdd", "__HIP_PLATFORM", "cooperative_groups", "mfma"):
+        assert banned not in code_only, banned
+    assert "#include <hip/hip_runtime.h>" in code
+
+
+def test_file_namespace_and_flags(tmp_path, robots):
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        gen = GRiDCodeGenerator(robots("mixed5"), False, True, True, "mygrid")   # positional ctor args as in the reference
+        gen.gen_all_code()
+        assert os.path.exists("mygrid.hip.h")
+        assert "namespace mygrid {" in gen.code_str and "void printMat(" in gen.code_str
+        with pytest.raises(NotImplementedError):
+            gen.gen_all_code(use_thread_group=True)
+    finally:
+        os.chdir(cwd)
+
+
+def test_generation_is_deterministic(robots):
+    import tempfile
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as d:
+        os.chdir(d)
+        try:
+            a = GRiDCodeGenerator(robots("mixed5")); a.gen_all_code()
+            b = GRiDCodeGenerator(robots("mixed5")); b.gen_all_code()
+        finally:
+            os.chdir(cwd)
+    assert a.code_str == b.code_str

@@ -1,0 +1,75 @@
+"""Emitted header compiled for the HOST and run on the CPU (tests/host_harness.cpp): checks the generated
+C++ text -- cores, _device wrappers and the pointer-style _inner tier -- against the oracle without a GPU."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import make_inputs, relerr
+from gridcodegenerator_amd import host
+from oracle import rbd_oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FP = ctypes.POINTER(ctypes.c_float)
+
+
+def _p(a):
+    return a.ctypes.data_as(FP)
+
+
+@pytest.fixture(scope="module", params=["iiwa7", "mixed5"])
+def harness(request, tmp_path_factory, robots):
+    name = request.param
+    d = tmp_path_factory.mktemp("hh_" + name)
+    header = str(d / ("grid_%s.hip.h" % name))
+    host.generate_header(robots(name), header, "grid_" + name)
+    so = str(d / "libhh.so")
+    cmd = [host._hipcc(), "--offload-host-only", "-O2", "-march=native", "-fPIC", "-shared", "-std=c++17",
+           "-DGRID_HEADER=\"%s\"" % header, "-DGRID_NS=grid_" + name, "-x", "hip", os.path.join(HERE, "host_harness.cpp"), "-o", so]
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert proc.returncode == 0, proc.stdout[-3000:]
+    return name, ctypes.CDLL(so)
+
+
+def test_host_compiled_header(harness, tables):
+    name, lib = harness
+    T = tables(name)
+    n = lib.hh_num_joints()
+    K = 16
+    q, qd, u = make_inputs(n, K, 21)
+    x = np.ascontiguousarray(np.concatenate([q, qd, u], axis=1))
+    q64, qd64, u64 = (a.astype(np.float64) for a in (q, qd, u))
+    g = ctypes.c_float(9.81)
+
+    ref_df, parts = O.fd_grad(T, q64, qd64, u64, return_parts=True)
+    ref_df = np.concatenate([O.flat_colmajor(ref_df[:, :, :n]), O.flat_colmajor(ref_df[:, :, n:])], axis=1)
+    out = np.zeros((K, 2 * n * n), dtype=np.float32)
+    lib.hh_fd_grad_f64(_p(x), _p(out), K, g)
+    assert relerr(out, ref_df)[0] < 2e-7          # fp64 arithmetic, fp32 rounding of the result only
+    lib.hh_fd_grad_f32(_p(x), _p(out), K, g)
+    assert relerr(out, ref_df)[0] < 1e-5          # fp32 arithmetic
+
+    c = np.zeros((K, n), dtype=np.float32)
+    lib.hh_id(_p(x), None, _p(c), K, g)
+    assert relerr(c, O.rnea(T, q64, qd64)[0])[0] < 2e-6
+    qdd = np.ascontiguousarray((0.7 * u).astype(np.float32))   # (qdd = FD(u) would make c = u by cancellation)
+    lib.hh_id(_p(x), _p(qdd), _p(c), K, g)
+    assert relerr(c, O.rnea(T, q64, qd64, qdd.astype(np.float64))[0])[0] < 2e-6
+
+    Mi = np.zeros((K, n * n), dtype=np.float32)
+    lib.hh_minv(_p(x), _p(Mi), K)
+    assert relerr(Mi, O.flat_colmajor(O.minv(T, q64, False)))[0] < 5e-6
+
+    acc = np.zeros((K, n), dtype=np.float32)
+    lib.hh_fd(_p(x), _p(acc), K, g)
+    assert relerr(acc, parts["qdd"])[0] < 2e-5
+
+    # _inner tier, chained like the reference's fused kernel
+    qdd_o = np.zeros((K, n), dtype=np.float32); dc = np.zeros((K, 2 * n * n), dtype=np.float32)
+    lib.hh_inner_chain(_p(x), _p(qdd_o), _p(dc), K, g)
+    assert relerr(qdd_o, parts["qdd"])[0] < 2e-5
+    ref_dc = O.rnea_grad(T, q64, qd64, qdd_o.astype(np.float64))
+    ref_dc = np.concatenate([O.flat_colmajor(ref_dc[:, :, :n]), O.flat_colmajor(ref_dc[:, :, n:])], axis=1)
+    assert relerr(dc, ref_dc)[0] < 5e-6

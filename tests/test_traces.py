@@ -1,0 +1,127 @@
+"""The traced cores (what one lane executes) interpreted on the CPU against the oracle -- no compiler,
+no GPU: float64 proves the algorithm + sparsity specialisation are exact; emulated fp32 (fused
+multiply-add, float storage) bounds the round-off the HIP kernels will show."""
+import numpy as np
+import pytest
+
+from conftest import make_inputs, relerr
+from gridcodegenerator_amd.emit import cores
+from gridcodegenerator_amd.emit.model import RobotSpec
+from oracle import rbd_oracle as O
+
+K = 6
+
+
+def _inputs(n, q, qd, u=None, qdd=None, Minv_flat=None, style="core"):
+    d = {"gravity": np.full(q.shape[0], 9.81)}
+    for j in range(n):
+        d["in.q(%d)" % j] = q[:, j]; d["in.qd(%d)" % j] = qd[:, j]
+        if u is not None:
+            d["in.u(%d)" % j] = u[:, j]
+        if qdd is not None:
+            d["in.qdd(%d)" % j] = qdd[:, j]
+    if Minv_flat is not None:
+        for i in range(n * n):
+            d["in.Minv(%d)" % i] = Minv_flat[:, i]
+    return d
+
+
+def _run(tr, inputs, dtype="float64"):
+    Kb = len(inputs["gravity"])
+    return np.stack([np.broadcast_to(o, (Kb,)) for o in tr.evaluate(inputs, dtype)], axis=1)
+
+
+def _grad_flat(M, n):
+    return np.concatenate([O.flat_colmajor(M[:, :, :n]), O.flat_colmajor(M[:, :, n:])], axis=1)
+
+
+@pytest.fixture(scope="module")
+def setup(robots, tables):
+    def make(name):
+        spec = RobotSpec(robots(name))
+        q, qd, u = (a.astype(np.float64) for a in make_inputs(spec.n, K, 11))
+        return spec, tables(name), q, qd, u
+    return make
+
+
+def test_rnea_core(robot_name, setup):
+    spec, T, q, qd, u = setup(robot_name)
+    qdd = u * 0.7
+    for use_qdd in (False, True):
+        tr = cores.core_inverse_dynamics(spec, use_qdd)
+        got = _run(tr, _inputs(spec.n, q, qd, qdd=qdd if use_qdd else None))
+        ref = O.rnea(T, q, qd, qdd if use_qdd else None)[0]
+        assert relerr(got, ref)[0] < 1e-13
+
+
+def test_vaf_core(robot_name, setup):
+    spec, T, q, qd, u = setup(robot_name)
+    n = spec.n
+    tr = cores.core_inverse_dynamics_vaf(spec, True)
+    got = _run(tr, _inputs(n, q, qd, qdd=u))
+    c, v, a, f = O.rnea(T, q, qd, u)
+    ref = np.concatenate([v.reshape(K, 6 * n), a.reshape(K, 6 * n), f.reshape(K, 6 * n)], axis=1)
+    assert relerr(got, ref)[0] < 1e-13
+
+
+def test_minv_core(robot_name, setup):
+    spec, T, q, qd, u = setup(robot_name)
+    got = _run(cores.core_direct_minv(spec), _inputs(spec.n, q, qd))
+    ref = O.flat_colmajor(O.minv(T, q, False))
+    assert relerr(got, ref)[0] < 1e-13
+    n = spec.n
+    lower = [n * c + r for c in range(n) for r in range(n) if r > c]
+    assert np.all(got[:, lower] == 0.0)  # upper triangular output, lower half written as 0
+
+
+def test_forward_dynamics_core(robot_name, setup):
+    spec, T, q, qd, u = setup(robot_name)
+    got = _run(cores.core_forward_dynamics(spec), _inputs(spec.n, q, qd, u=u))
+    assert relerr(got, O.forward_dynamics(T, q, qd, u))[0] < 1e-12
+
+
+def test_rnea_gradient_core(robot_name, setup):
+    spec, T, q, qd, u = setup(robot_name)
+    for use_qdd in (False, True):
+        tr = cores.core_inverse_dynamics_gradient(spec, use_qdd)
+        got = _run(tr, _inputs(spec.n, q, qd, qdd=u if use_qdd else None))
+        ref = _grad_flat(O.rnea_grad(T, q, qd, u if use_qdd else None), spec.n)
+        assert relerr(got, ref)[0] < 1e-13
+
+
+def test_fd_gradient_core(robot_name, setup):
+    spec, T, q, qd, u = setup(robot_name)
+    ref, parts = O.fd_grad(T, q, qd, u, return_parts=True)
+    ref = _grad_flat(ref, spec.n)
+    got = _run(cores.core_forward_dynamics_gradient(spec, False), _inputs(spec.n, q, qd, u=u))
+    assert relerr(got, ref)[0] < 1e-12
+    # variant with qdd and upper-triangular Minv supplied (reference USE_QDD_MINV_FLAG)
+    Mup = O.flat_colmajor(np.triu(parts["Minv"]))
+    got2 = _run(cores.core_forward_dynamics_gradient(spec, True), _inputs(spec.n, q, qd, qdd=parts["qdd"], Minv_flat=Mup))
+    assert relerr(got2, ref)[0] < 1e-12
+
+
+def test_structural_zeros_are_folded(robots):
+    """dc_du[j, col] vanishes unless col is an ancestor of j or in its subtree; the generator must know it."""
+    spec = RobotSpec(robots("atlas30"))
+    tr = cores.core_inverse_dynamics_gradient(spec, True)
+    n = spec.n
+    const_zero = sum(1 for (_, r) in tr.outputs if isinstance(r, float) and r == 0.0)
+    related = sum(len(spec.ancestors[j]) + len(spec.subtree[j]) for j in range(n))
+    assert const_zero >= 2 * (n * n - related)  # (+ columns the dynamics is invariant to, e.g. base yaw)
+
+
+def test_op_counts_beat_dense(robots):
+    """Generation-time sparsity: far fewer flops than the dense 6x6 count of SURVEY.md section 8(d)."""
+    assert cores.core_forward_dynamics_gradient(RobotSpec(robots("iiwa7")), False).flops() < 0.5 * 41000
+    assert cores.core_forward_dynamics_gradient(RobotSpec(robots("atlas30")), False).flops() < 0.5 * 337000
+
+
+@pytest.mark.parametrize("name,bound", [("iiwa7", 3e-6), ("atlas30", 1e-5)])
+def test_fp32_roundoff_budget(name, bound, setup):
+    """Emulated fp32: the norm-wise error of df_du stays at the level of the reference's own fp32
+    kernels or better (2.4e-5 / 5.9e-5)."""
+    spec, T, q, qd, u = setup(name)
+    ref = _grad_flat(O.fd_grad(T, q, qd, u), spec.n)
+    got = _run(cores.core_forward_dynamics_gradient(spec, False), _inputs(spec.n, q, qd, u=u), "float32")
+    assert relerr(got, ref)[0] < bound
