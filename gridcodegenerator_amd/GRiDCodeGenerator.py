@@ -14,6 +14,9 @@ Generation-time knobs that have no reference counterpart are keyword-only:
     out_chunk                         max values per configuration staged in LDS per coalesced flush
     emit_order       "demand" | "creation"  ordering of the straight-line bodies
     emit_inner_api                    also emit the pointer-style ``_inner`` tier (API parity)
+    fence_every                       extra scheduling fence every N emitted statements (0 = none).  A fence always
+                                      follows each output store: without it hipcc's machine scheduler hoists every
+                                      output's dot product above the stores (iiwa-7 FD gradient: 472 vs 257 registers)
 """
 from .algorithms._emit import AlgorithmEmitMixin
 from .emit.model import RobotSpec
@@ -24,7 +27,7 @@ from .helpers._text import TextMixin
 class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin):
     def __init__(self, robotObj, DEBUG_MODE=False, NEED_PRINT_MAT=False, USE_DYNAMIC_SHARED_MEM=True,
                  FILE_NAMESPACE="grid", *, precision="fp32", trig="f32", suggested_threads=64, max_threads=256,
-                 out_chunk=64, emit_order="demand", emit_inner_api=True, suggested_max_blocks=2048):
+                 out_chunk=64, emit_order="demand", emit_inner_api=True, suggested_max_blocks=2048, fence_every=0):
         if precision not in ("fp32", "fp64"):
             raise ValueError("precision must be 'fp32' or 'fp64'")
         if trig not in ("f32", "f64"):
@@ -47,6 +50,7 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin):
         self.suggested_max_blocks = int(suggested_max_blocks)
         self.out_chunk = int(out_chunk)
         self.emit_order = emit_order
+        self.fence_every = int(fence_every)
         self.emit_inner_api = bool(emit_inner_api)
         self.core_stats = {}
         self.trace_stats = {}

@@ -55,7 +55,7 @@ class AlgorithmEmitMixin:
         self.gen_add_code_line(qualifiers)
         self.gen_add_code_line(signature + " {", True)
         ind = "    " * self.indent_level
-        lines = tracer.emit(indent=ind, order=self.emit_order, store=store)
+        lines = tracer.emit(indent=ind, order=self.emit_order, store=store, fence_every=self.fence_every)
         self.gen_add_raw("\n".join(lines))
         self.gen_add_end_function()
         self.trace_stats[signature.split("(")[0].split()[-1] + "/" + str(len(self.trace_stats))] = tracer.op_counts()
@@ -70,13 +70,13 @@ class AlgorithmEmitMixin:
             "template <typename T, typename C, typename In, typename Out>",
             "__host__ __device__ __forceinline__",
             "void %s(const In &in, Out &out, const T gravity)" % name, tracer,
-            store=lambda dst, val: "out.put(%s, (T)(%s));" % (dst, val))
+            store=lambda dst, val: "out.put(%s, (T)(%s)); GRID_SCHED_FENCE();" % (dst, val))
 
     def _emit_load(self, dst, src, total, stride):
         off = 0
         while off < total:
             p = min(MAX_IN_PIECE, total - off)
-            self.gen_add_code_line("grid_load_tile<T,%d,%d>(%s + %d, %s + %d, %s, k0, it.lane, NUM_TIMESTEPS, s_wave, it.staged);"
+            self.gen_add_code_line("grid_load_tile<T,%d,%d>(%s + %d, %s + %d, %s, k0, it, NUM_TIMESTEPS, s_wave);"
                                    % (p, self._pad(p), dst, off, src, off, stride))
             off += p
 
@@ -99,7 +99,7 @@ class AlgorithmEmitMixin:
         params.append("NUM_TIMESTEPS is the number of configurations")
         self.gen_add_func_doc(doc, ["lane-per-configuration: each wavefront owns 64 consecutive configurations per tile",
                                     "launch with <<<blocks, SUGGESTED_THREADS, %s_DYNAMIC_SHARED_MEM_COUNT*sizeof(T)>>>; any block shape up to"
-                                    % alg, "GRID_MAX_THREADS threads is accepted (shapes that are not whole waves fall back to unstaged I/O)"],
+                                    % alg, "GRID_MAX_THREADS threads is accepted (the dynamic LDS must cover ceil(threads/64) wave regions)"],
                               params, None)
         self.gen_add_code_line("template <typename T, typename C = typename grid_compute<T>::type>")
         self.gen_add_code_line("__global__ __launch_bounds__(GRID_MAX_THREADS)")
@@ -117,7 +117,7 @@ class AlgorithmEmitMixin:
             self.gen_add_code_line("T s_%s[%d];" % (ename, ecount))
             self._emit_load("s_" + ename, "d_" + ename, ecount, str(ecount))
         self.gen_add_code_line("const grid_in_ptrs<T> in = {%s};" % accessor)
-        self.gen_add_code_line("grid_out_staged<T,%d,%d,%d> out = {s_wave, d_%s, k0, it.lane, NUM_TIMESTEPS, it.staged};"
+        self.gen_add_code_line("grid_out_staged<T,%d,%d,%d> out = {s_wave, d_%s, k0, it.lane, it.W, NUM_TIMESTEPS};"
                                % (n_out, ch, self._pad(ch), out_name))
         self.gen_add_code_line("%s<T,C>(in, out, %s);" % (core, "gravity" if has_gravity else "static_cast<T>(0)"))
         self.gen_add_end_control_flow()
@@ -174,13 +174,12 @@ class AlgorithmEmitMixin:
             "    }",
             "    else {*blocks = block_dimms; *threads = thread_dimms;}",
             "}",
-            "/** Dynamic LDS bytes for a block of `threads` (whole waves; 0 if the kernel will run unstaged). */",
+            "/** Dynamic LDS bytes for a block of `threads`: one staging region per (possibly partial) wavefront. */",
             "template <typename T>",
             "__host__ inline",
             "size_t grid_lds_bytes(const dim3 threads, const int elems_per_wave){",
             "    const int nthreads = threads.x*threads.y*threads.z;",
-            "    if ((nthreads % GRID_WAVE_SIZE) != 0 || nthreads > SUGGESTED_THREADS){return 0;}",
-            "    return (size_t)(nthreads/GRID_WAVE_SIZE)*elems_per_wave*sizeof(T);",
+            "    return (size_t)((nthreads + GRID_WAVE_SIZE - 1)/GRID_WAVE_SIZE)*elems_per_wave*sizeof(T);",
             "}",
             "",
         ])

@@ -199,25 +199,25 @@ static int launch_alg(grid_handle *h, int alg, float *d_out, const float *d_in, 
     launch_shape(K, blocks, threads, &b, &t);
     switch (alg) {
     case GRID_ALG_ID: {
-        const size_t lds = G::grid_lds_bytes<T>(t, G::ID_DYNAMIC_SHARED_MEM_COUNT / (G::SUGGESTED_THREADS / G::GRID_WAVE_SIZE));
+        const size_t lds = G::grid_lds_bytes<T>(t, G::ID_DYNAMIC_SHARED_MEM_COUNT / (G::GRID_MAX_THREADS / G::GRID_WAVE_SIZE));
         if (d_qdd) G::inverse_dynamics_kernel<T><<<b, t, lds, s>>>(d_out, d_in, stride, d_qdd, h->d_robotModel, gravity, K);
         else       G::inverse_dynamics_kernel<T><<<b, t, lds, s>>>(d_out, d_in, stride, h->d_robotModel, gravity, K);
         break; }
     case GRID_ALG_MINV: {
-        const size_t lds = G::grid_lds_bytes<T>(t, G::MINV_DYNAMIC_SHARED_MEM_COUNT / (G::SUGGESTED_THREADS / G::GRID_WAVE_SIZE));
+        const size_t lds = G::grid_lds_bytes<T>(t, G::MINV_DYNAMIC_SHARED_MEM_COUNT / (G::GRID_MAX_THREADS / G::GRID_WAVE_SIZE));
         G::direct_minv_kernel<T><<<b, t, lds, s>>>(d_out, d_in, stride, h->d_robotModel, K);
         break; }
     case GRID_ALG_FD: {
-        const size_t lds = G::grid_lds_bytes<T>(t, G::FD_DYNAMIC_SHARED_MEM_COUNT / (G::SUGGESTED_THREADS / G::GRID_WAVE_SIZE));
+        const size_t lds = G::grid_lds_bytes<T>(t, G::FD_DYNAMIC_SHARED_MEM_COUNT / (G::GRID_MAX_THREADS / G::GRID_WAVE_SIZE));
         G::forward_dynamics_kernel<T><<<b, t, lds, s>>>(d_out, d_in, stride, h->d_robotModel, gravity, K);
         break; }
     case GRID_ALG_ID_DU: {
-        const size_t lds = G::grid_lds_bytes<T>(t, G::ID_DU_DYNAMIC_SHARED_MEM_COUNT / (G::SUGGESTED_THREADS / G::GRID_WAVE_SIZE));
+        const size_t lds = G::grid_lds_bytes<T>(t, G::ID_DU_DYNAMIC_SHARED_MEM_COUNT / (G::GRID_MAX_THREADS / G::GRID_WAVE_SIZE));
         if (d_qdd) G::inverse_dynamics_gradient_kernel<T><<<b, t, lds, s>>>(d_out, d_in, stride, d_qdd, h->d_robotModel, gravity, K);
         else       G::inverse_dynamics_gradient_kernel<T><<<b, t, lds, s>>>(d_out, d_in, stride, h->d_robotModel, gravity, K);
         break; }
     case GRID_ALG_FD_DU: {
-        const size_t lds = G::grid_lds_bytes<T>(t, G::FD_DU_DYNAMIC_SHARED_MEM_COUNT / (G::SUGGESTED_THREADS / G::GRID_WAVE_SIZE));
+        const size_t lds = G::grid_lds_bytes<T>(t, G::FD_DU_DYNAMIC_SHARED_MEM_COUNT / (G::GRID_MAX_THREADS / G::GRID_WAVE_SIZE));
         if (d_qdd && d_Minv) G::forward_dynamics_gradient_kernel<T><<<b, t, lds, s>>>(d_out, d_in, stride, d_qdd, d_Minv, h->d_robotModel, gravity, K);
         else                 G::forward_dynamics_gradient_kernel<T><<<b, t, lds, s>>>(d_out, d_in, stride, h->d_robotModel, gravity, K);
         break; }

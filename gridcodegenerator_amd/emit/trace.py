@@ -231,13 +231,16 @@ class Tracer:
             return self._lit(r)
         return ("t%d" % r) if r > 0 else ("-t%d" % (-r))
 
-    def emit(self, indent="    ", order="demand", store=None, after_store=None):
+    def emit(self, indent="    ", order="demand", store=None, after_store=None, fence_every=0):
         """C++ statements (compute type ``C``, storage type ``T``) for all live nodes + output stores.
 
         order="demand": outputs are visited in order and each pulls in (post-order) whatever it still
         needs, so a value is computed close to its first use -- this keeps live ranges short in the
         long matrix-product tails.  order="creation": nodes in trace order, all stores at the end.
         store(dst, value_expr) -> statement; after_store(i) -> optional extra statement after output i.
+        fence_every=N > 0 inserts ``GRID_SCHED_FENCE();`` every N statements: the emitted order already keeps
+        live ranges short, and without fences hipcc's machine scheduler re-orders the single giant basic block
+        for ILP and doubles the register pressure (measured: iiwa-7 FD gradient 472 -> 257 registers).
         """
         live = self.live_nodes()
         if store is None:
@@ -248,10 +251,14 @@ class Tracer:
                 trig_args.setdefault(self.nodes[k][1], {})[self.nodes[k][0]] = k
         emitted = [False] * len(self.nodes)
         lines = []
+        count = [0]
 
         def emit_node(k):
             op, a, b, c = self.nodes[k]
             emitted[k] = True
+            count[0] += 1
+            if fence_every and count[0] % fence_every == 0:
+                lines.append(indent + "GRID_SCHED_FENCE();")
             if op == "in":
                 lines.append("%sconst C t%d = (C)%s;" % (indent, k, a))
             elif op == "mul":

@@ -30,6 +30,12 @@ class RuntimeEmitMixin:
             "#include <stdlib.h>",
             "#include <time.h>",
             "#include <hip/hip_runtime.h>",
+            "// scheduling fence used inside the straight-line bodies (device code only)",
+            "#if defined(__HIP_DEVICE_COMPILE__)",
+            "#define GRID_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)",
+            "#else",
+            "#define GRID_SCHED_FENCE()",
+            "#endif",
             "// single kernel timing helper code",
             "#define time_delta_us_timespec(start,end) (1e6*static_cast<double>(end.tv_sec - start.tv_sec)+1e-3*static_cast<double>(end.tv_nsec - start.tv_nsec))",
             "",
@@ -91,11 +97,12 @@ class RuntimeEmitMixin:
 
     def gen_add_constants_helpers(self):
         n = self.spec.n
-        waves = self.suggested_threads // WAVE
+        waves = self.max_threads // WAVE  # any legal block shape may be launched with the documented LDS size
         self.gen_add_code_lines([
             "const int NUM_JOINTS = %d;" % n,
             "// lane-per-configuration: one wavefront (64 lanes) stages 64 configurations through LDS;",
-            "// <ALG>_DYNAMIC_SHARED_MEM_COUNT is what a block of SUGGESTED_THREADS threads needs (in T elements)",
+            "// <ALG>_DYNAMIC_SHARED_MEM_COUNT is what a block of up to GRID_MAX_THREADS threads needs (in T elements);",
+            "// the host wrappers request only ceil(threads/64) wave regions (grid_lds_bytes)",
             "const int GRID_WAVE_SIZE = %d;" % WAVE,
             "const int ID_DYNAMIC_SHARED_MEM_COUNT = %d;" % (waves * self.lds_per_wave("ID")),
             "const int MINV_DYNAMIC_SHARED_MEM_COUNT = %d;" % (waves * self.lds_per_wave("MINV")),
@@ -186,84 +193,77 @@ class RuntimeEmitMixin:
             "    __host__ __device__ __forceinline__ void put(int i, T v){p_[i] = v;}",
             "};",
             "",
-            "// ---- wave-level staging: 64 lanes <-> 64 consecutive configurations, no block barrier ----",
+            "// ---- wave-level staging: W lanes <-> W consecutive configurations (W = 64 for whole waves), no block barrier ----",
             "__device__ __forceinline__ void grid_wave_sync(){",
-            "    __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\");",
+            "    // orders this wave's LDS writes before its LDS reads across lanes.  Workgroup scope (not wavefront) on purpose:",
+            "    // if the compiler ever turns an LDS access into a FLAT one, FLAT and DS operations of one wave may complete",
+            "    // out of order, and only the workgroup-scope fence makes it wait for both counters.",
+            "    __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"workgroup\");",
             "    __builtin_amdgcn_wave_barrier();",
-            "    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");",
+            "    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"workgroup\");",
             "}",
-            "/**",
-            " * Load N values for each of the wave's 64 configurations (k0 .. k0+63, row stride `stride`).",
-            " * staged: flat coalesced global reads -> LDS (per-lane stride NPAD, odd => conflict free) -> registers.",
-            " * !staged: each lane reads its own row directly (any block shape; not coalesced).",
-            " * Lanes past NUM_TIMESTEPS receive zeros (staged) / a clamped row (direct) and never store.",
-            " */",
-            "template <typename T, int N, int NPAD>",
-            "__device__ __forceinline__ void grid_load_tile(T *dst, const T *d_src, const int stride, const int k0, const int lane,",
-            "                                               const int NUM_TIMESTEPS, T *s_wave, const bool staged){",
-            "    if (staged){",
-            "        const int nvalid = min(GRID_WAVE_SIZE, NUM_TIMESTEPS - k0);",
-            "        const T *src = d_src + (size_t)k0*stride;",
-            "        // rolled on purpose: fully unrolled, the per-t (cfg, i) address pairs are loop invariant and get",
-            "        // hoisted out of the tile loop, pinning N extra registers across the whole straight-line core",
-            "        #pragma unroll 4",
-            "        for (int t = 0; t < N; t++){",
-            "            const int f = t*GRID_WAVE_SIZE + lane; const int cfg = f / N; const int i = f - cfg*N;",
-            "            T v = static_cast<T>(0);",
-            "            if (cfg < nvalid){v = src[(size_t)cfg*stride + i];}",
-            "            s_wave[cfg*NPAD + i] = v;",
-            "        }",
-            "        grid_wave_sync();",
-            "        #pragma unroll",
-            "        for (int i = 0; i < N; i++){dst[i] = s_wave[lane*NPAD + i];}",
-            "        grid_wave_sync();",
-            "    }",
-            "    else {",
-            "        const int k = min(k0 + lane, NUM_TIMESTEPS - 1);",
-            "        #pragma unroll",
-            "        for (int i = 0; i < N; i++){dst[i] = d_src[(size_t)k*stride + i];}",
-            "    }",
-            "}",
-            "/**",
-            " * Output sink of a kernel: put(i, v) in increasing i.  Values collect in LDS CH at a time and every full",
-            " * chunk is written out flat (consecutive lanes -> consecutive addresses inside each configuration's run of",
-            " * CH values), so the N_OUT*64 results of a wave leave as wide contiguous stores instead of 64-way strided ones.",
-            " */",
-            "template <typename T, int N_OUT, int CH, int CHPAD>",
-            "struct grid_out_staged {",
-            "    T *s_wave; T *d_dst; int k0; int lane; int NUM_TIMESTEPS; bool staged;",
-            "    __device__ __forceinline__ void flush(const int chunk){",
-            "        const int base = chunk*CH; const int len = (N_OUT - base < CH) ? (N_OUT - base) : CH;",
-            "        const int nvalid = min(GRID_WAVE_SIZE, NUM_TIMESTEPS - k0);",
-            "        grid_wave_sync();",
-            "        T *dst = d_dst + (size_t)k0*N_OUT + base;",
-            "        #pragma unroll 4",
-            "        for (int t = 0; t < len; t++){",
-            "            const int f = t*GRID_WAVE_SIZE + lane; const int cfg = f / len; const int i = f - cfg*len;",
-            "            if (cfg < nvalid){dst[(size_t)cfg*N_OUT + i] = s_wave[cfg*CHPAD + i];}",
-            "        }",
-            "        grid_wave_sync();",
-            "    }",
-            "    __device__ __forceinline__ void put(const int i, const T v){",
-            "        if (staged){",
-            "            s_wave[lane*CHPAD + (i % CH)] = v;",
-            "            if (((i + 1) % CH) == 0 || i == N_OUT - 1){flush(i / CH);}",
-            "        }",
-            "        else if (k0 + lane < NUM_TIMESTEPS){d_dst[(size_t)(k0 + lane)*N_OUT + i] = v;}",
-            "    }",
-            "};",
-            "/** Wave/tile bookkeeping shared by every kernel (flat thread ids; any grid/block shape is accepted). */",
+            "/** Wave/tile bookkeeping shared by every kernel (flat thread ids; any grid/block shape up to GRID_MAX_THREADS). */",
             "struct grid_tile_iter {",
-            "    int lane; int k0_first; int k0_step; bool staged; int wave_in_block;",
+            "    int lane; int W; int k0_first; int k0_step; int wave_in_block;",
             "    __device__ __forceinline__ grid_tile_iter(){",
             "        const int nthreads = blockDim.x*blockDim.y*blockDim.z;",
             "        const int tid = threadIdx.x + blockDim.x*(threadIdx.y + blockDim.y*threadIdx.z);",
             "        const int nblocks = gridDim.x*gridDim.y*gridDim.z;",
             "        const int bid = blockIdx.x + gridDim.x*(blockIdx.y + gridDim.y*blockIdx.z);",
-            "        lane = tid & (GRID_WAVE_SIZE - 1); wave_in_block = tid / GRID_WAVE_SIZE;",
-            "        k0_first = bid*nthreads + (tid - lane); k0_step = nblocks*nthreads;",
-            "        // LDS staging needs whole waves and a block no larger than the LDS was sized for",
-            "        staged = ((nthreads % GRID_WAVE_SIZE) == 0) && (nthreads <= SUGGESTED_THREADS);",
+            "        lane = tid & (GRID_WAVE_SIZE - 1);",
+            "        // wave-uniform by construction; readfirstlane tells the compiler so (SGPRs, scalar loop control)",
+            "        wave_in_block = __builtin_amdgcn_readfirstlane(tid / GRID_WAVE_SIZE);",
+            "        W = min(GRID_WAVE_SIZE, nthreads - wave_in_block*GRID_WAVE_SIZE); // lanes of this wave (partial last wave allowed)",
+            "        k0_first = bid*nthreads + wave_in_block*GRID_WAVE_SIZE; k0_step = nblocks*nthreads;",
+            "    }",
+            "};",
+            "/**",
+            " * Load N values for each of the wave's W configurations (k0 .. k0+W-1, row stride `stride`):",
+            " * flat coalesced global reads -> LDS (per-lane stride NPAD, odd => conflict free) -> lane-private registers.",
+            " * Lanes past NUM_TIMESTEPS receive zeros and never store.",
+            " */",
+            "template <typename T, int N, int NPAD>",
+            "__device__ __forceinline__ void grid_load_tile(T *dst, const T *d_src, const int stride, const int k0, const grid_tile_iter &it,",
+            "                                               const int NUM_TIMESTEPS, T *s_wave){",
+            "    const int nvalid = min(it.W, NUM_TIMESTEPS - k0);",
+            "    const T *src = d_src + (size_t)k0*stride;",
+            "    // rolled on purpose: fully unrolled, the per-t (cfg, i) address pairs are loop invariant and get",
+            "    // hoisted out of the tile loop, pinning N extra registers across the whole straight-line core",
+            "    #pragma unroll 4",
+            "    for (int t = 0; t < N; t++){",
+            "        const int f = t*it.W + it.lane; const int cfg = f / N; const int i = f - cfg*N;",
+            "        T v = static_cast<T>(0);",
+            "        if (cfg < nvalid){v = src[(size_t)cfg*stride + i];}",
+            "        s_wave[cfg*NPAD + i] = v;",
+            "    }",
+            "    grid_wave_sync();",
+            "    #pragma unroll",
+            "    for (int i = 0; i < N; i++){dst[i] = s_wave[it.lane*NPAD + i];}",
+            "    grid_wave_sync();",
+            "}",
+            "/**",
+            " * Output sink of a kernel: put(i, v) in increasing i.  Values collect in LDS CH at a time and every full",
+            " * chunk is written out flat (consecutive lanes -> consecutive addresses inside each configuration's run of",
+            " * CH values), so the N_OUT*W results of a wave leave as wide contiguous stores instead of W-way strided ones.",
+            " */",
+            "template <typename T, int N_OUT, int CH, int CHPAD>",
+            "struct grid_out_staged {",
+            "    T *s_wave; T *d_dst; int k0; int lane; int W; int NUM_TIMESTEPS;",
+            "    __device__ __forceinline__ void flush(const int chunk){",
+            "        const int base = chunk*CH; const int len = (N_OUT - base < CH) ? (N_OUT - base) : CH;",
+            "        const int nvalid = min(W, NUM_TIMESTEPS - k0);",
+            "        grid_wave_sync();",
+            "        T *dst = d_dst + (size_t)k0*N_OUT + base;",
+            "        #pragma unroll 4",
+            "        for (int t = 0; t < len; t++){",
+            "            const int f = t*W + lane; const int cfg = f / len; const int i = f - cfg*len;",
+            "            if (cfg < nvalid){dst[(size_t)cfg*N_OUT + i] = s_wave[cfg*CHPAD + i];}",
+            "        }",
+            "        grid_wave_sync();",
+            "    }",
+            "    __device__ __forceinline__ void put(const int i, const T v){",
+            "        s_wave[lane*CHPAD + (i % CH)] = v;",
+            "        if (((i + 1) % CH) == 0 || i == N_OUT - 1){flush(i / CH);}",
             "    }",
             "};",
             "",

@@ -8,8 +8,8 @@ kernels compute in fp32 and store fp32.  Norm-wise = max|err| / max|ref| over th
                                          reference's own fp32 kernels reach 2.2e-6 .. 6.2e-6)
     dc_du                        5e-6
     df_du                        3e-5   (reference's own fp32 kernels: 2.4e-5 / 5.9e-5)
-The fp64-compute build of the same generator (precision="fp64") is held to 2e-7 on everything: only
-the final rounding to fp32 remains.
+(The generator can also emit fp64 arithmetic, precision="fp64"; that build is checked on the CPU in
+tests/test_host_compiled.py (2e-7) but is NOT shipped for the GPU this round: see DESIGN.md "fp64".)
 """
 import numpy as np
 import pytest
@@ -19,7 +19,6 @@ from conftest import make_inputs, relerr
 pytestmark = pytest.mark.gpu
 
 TOL32 = dict(c=2e-6, Minv=5e-6, qdd=3e-5, dc_du=5e-6, df_du=3e-5)
-TOL64 = dict(c=2e-7, Minv=2e-7, qdd=2e-7, dc_du=2e-7, df_du=2e-7)
 G = 9.81
 
 
@@ -62,13 +61,10 @@ def pack(q, qd, u):
 
 
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("precision", ["fp32", "fp64"])
-def test_all_algorithms_host_api(robot_name, precision, handles, tables):
+def test_all_algorithms_host_api(robot_name, handles, tables):
     """Every host wrapper (reference mode 0) on a ragged batch (3 full tiles + 9)."""
-    if precision == "fp64" and robot_name == "atlas30":
-        pytest.skip("fp64 build of atlas30 is not part of the default build set")
-    h = handles(robot_name, precision)
-    tol = TOL32 if precision == "fp32" else TOL64
+    h = handles(robot_name)
+    tol = TOL32
     n, K = h.n, 201
     q, qd, u = make_inputs(n, K, 31)
     ref = oracle_all(tables(robot_name), q, qd, u)
@@ -134,8 +130,8 @@ def test_ragged_sizes_device_api(K, handles, tables, torch_cuda):
 
 
 def test_launch_shapes_agree_bitwise(handles, torch_cuda):
-    """Staged (whole waves, <= SUGGESTED_THREADS) and unstaged launch shapes, few blocks (grid-stride loop),
-    many blocks: identical arithmetic per lane => bit-identical results."""
+    """Whole-wave and partial-wave block shapes, few blocks (grid-stride tile loop), many blocks:
+    identical arithmetic per lane => bit-identical results."""
     torch = torch_cuda
     h = handles("iiwa7")
     n, K = h.n, 1000
