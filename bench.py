@@ -74,21 +74,15 @@ def main():
     args = ap.parse_args()
 
     import torch
-    from gridcodegenerator_amd import host
+    from gridcodegenerator_amd import host, sharding
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local_rank, world = sharding.env_rank()
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+    dist = sharding.init_distributed("nccl")
 
     host.build_library(args.robot, args.precision)
     h = host.GridHandle(args.robot, device=local_rank, precision=args.precision)
@@ -104,25 +98,7 @@ def main():
         h.forward_dynamics_gradient_device(d_out.data_ptr(), d_in.data_ptr(), 3 * n, K, gravity=GRAVITY,
                                            blocks=args.blocks, threads=args.threads, stream=stream)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = sharding.timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, dist, reduce_device="cuda")
 
     # in-stream kernel duration (HIP events recorded on the launch stream by the C ABI)
     kern_ms = h.time_device(host.ALG_FD_DU, d_out.data_ptr(), d_in.data_ptr(), 3 * n, K, gravity=GRAVITY,
@@ -130,14 +106,20 @@ def main():
     finite = bool(torch.isfinite(d_out).all().item())
 
     if rank == 0:
-        total_evals = float(world) * K * args.steps
+        value = sharding.aggregate_throughput(K, world, args.steps, elapsed)
+        traffic = None      # PMC counters cannot be read from inside the timed process; use the committed rocprofv3 pass
+        try:
+            with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as fh:
+                traffic = json.load(fh).get("%s:%d:forward_dynamics_gradient" % (args.robot, K), {}).get("bytes")
+        except OSError:
+            pass
         alg_bytes = host.algorithmic_bytes(host.ALG_FD_DU, n) * K
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         attrs = h.L.kernel_attributes(host.ALG_FD_DU)
         out = {
             "metric": "FD-gradient evals/sec (iiwa-7, batch=16k) + achieved HBM GB/s vs peak" if args.robot == "iiwa7" and K == 16384
                       else "FD-gradient evals/sec (%s, batch=%d)" % (args.robot, K),
-            "value": total_evals / elapsed, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": h.L.compute_dtype, "data": "synthetic",
             "config": {"workload": "%s forward_dynamics_gradient_kernel, batch %d per GPU, fp32 I/O, device-resident (reference _compute_only)"
@@ -148,7 +130,7 @@ def main():
                        "kernel": {"vgprs": attrs["numRegs"], "scratch_bytes_per_lane": attrs["scratch_bytes_per_lane"]},
                        "outputs_finite": finite},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": None, "kernel": "forward_dynamics_gradient_kernel", "kernel_avg_us": 1e3 * kern_ms,
+                         "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, profiles/)", "kernel": "forward_dynamics_gradient_kernel", "kernel_avg_us": 1e3 * kern_ms,
                          "algorithmic_bytes_per_eval": host.algorithmic_bytes(host.ALG_FD_DU, n),
                          "kernel_evals_per_s": K / (kern_ms * 1e-3)},
         }

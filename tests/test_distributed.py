@@ -1,0 +1,82 @@
+"""N > 1 host logic on the CPU with the gloo backend, world_size 2: shard assignment, barrier-bracketed
+timing with max-over-ranks, whole-job throughput -- exactly the functions bench.py uses on the GPUs
+(there with backend "nccl" = RCCL).  There is no data-path collective to test: shards never exchange data."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+from gridcodegenerator_amd import sharding
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_bounds_partition_the_batch():
+    for total in (1, 7, 16384, 1048576, 1000003):
+        for world in (1, 2, 3, 4, 8):
+            spans = [sharding.shard_bounds(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            for a, b in zip(spans, spans[1:]):
+                assert a[1] == b[0]
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert sharding.shard_bounds(1048576, 8, 3) == (393216, 524288)   # BASELINE.json configs[4]: 8 shards of 131072
+
+
+WORKER = textwrap.dedent("""
+    import json, os, sys, time
+    sys.path.insert(0, %(repo)r)
+    import numpy as np
+    from gridcodegenerator_amd import sharding
+    from gridcodegenerator_amd.robots import get_robot
+    from oracle import rbd_oracle as O
+    rank, local_rank, world = sharding.env_rank()
+    dist = sharding.init_distributed("gloo")
+    assert dist is not None and dist.get_world_size() == 2
+    total = 37
+    lo, hi = sharding.shard_bounds(total, world, rank)
+    rng = np.random.default_rng(5)
+    q = rng.uniform(-3, 3, (total, 7)); qd = rng.uniform(-1, 1, (total, 7)); u = rng.uniform(-1, 1, (total, 7))
+    T = O.RobotTables(get_robot("iiwa7"))
+    calls = []
+    def step():
+        calls.append(1)
+        time.sleep(0.02 * (rank + 1))          # rank 1 is the slow one
+    elapsed = sharding.timed_steps(step, steps=5, warmup=2, device_sync=lambda: None, dist=dist)
+    out = O.fd_grad(T, q[lo:hi], qd[lo:hi], u[lo:hi])    # this rank's shard only; nothing is exchanged
+    np.save(os.path.join(%(out)r, "shard%%d.npy" %% rank), out)
+    with open(os.path.join(%(out)r, "rank%%d.json" %% rank), "w") as fh:
+        json.dump(dict(rank=rank, lo=lo, hi=hi, elapsed=elapsed, calls=len(calls),
+                       value=sharding.aggregate_throughput(hi - lo, world, 5, elapsed)), fh)
+    dist.destroy_process_group()
+""")
+
+
+def test_two_rank_gloo_run(tmp_path, tables):
+    import json
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % dict(repo=REPO, out=str(tmp_path)))
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    info = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(2)]
+    assert (info[0]["lo"], info[0]["hi"], info[1]["lo"], info[1]["hi"]) == (0, 18, 18, 37)
+    assert info[0]["calls"] == info[1]["calls"] == 7                      # W=2 untimed + exactly K=5 timed steps
+    assert abs(info[0]["elapsed"] - info[1]["elapsed"]) < 1e-9            # both ranks hold the MAX over ranks
+    assert info[0]["elapsed"] >= 5 * 0.04 * 0.9                           # ... which is the slow rank's time
+    # concatenated shards == the un-sharded computation (no cross-shard coupling)
+    from oracle import rbd_oracle as O
+    rng = np.random.default_rng(5)
+    q = rng.uniform(-3, 3, (37, 7)); qd = rng.uniform(-1, 1, (37, 7)); u = rng.uniform(-1, 1, (37, 7))
+    full = O.fd_grad(tables("iiwa7"), q, qd, u)
+    got = np.concatenate([np.load(tmp_path / "shard0.npy"), np.load(tmp_path / "shard1.npy")])
+    assert np.array_equal(got, full)
