@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--cpu-passes", type=int, default=2)
     ap.add_argument("--blocks", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--split", type=int, default=0, help="column-split factor of the gradient kernel: 0 auto, 1 never, S force")
     ap.add_argument("--all-kernels", action="store_true", help="also time the other four kernels (reported under 'kernels')")
     args = ap.parse_args()
 
@@ -93,6 +94,8 @@ def main():
     d_in = torch.from_numpy(x).cuda()
     d_out = torch.empty((K, 2 * n * n), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
+    h.set_split(host.ALG_FD_DU, args.split)
+    split_used = h.get_split(host.ALG_FD_DU, K)
 
     def step():
         h.forward_dynamics_gradient_device(d_out.data_ptr(), d_in.data_ptr(), 3 * n, K, gravity=GRAVITY,
@@ -126,7 +129,8 @@ def main():
                                    % (args.robot, K),
                        "robot": args.robot, "num_joints": n, "batch_per_gpu": K, "global_batch": K * world,
                        "parallelism": "batch-sharded x%d, independent streams, no collective on the data path" % world,
-                       "launch": {"blocks": args.blocks or "suggested", "threads": args.threads or h.L.constants["SUGGESTED_THREADS"]},
+                       "launch": {"blocks": args.blocks or "suggested", "threads": args.threads or h.L.constants["SUGGESTED_THREADS"],
+                                  "column_split": split_used},
                        "kernel": {"vgprs": attrs["numRegs"], "scratch_bytes_per_lane": attrs["scratch_bytes_per_lane"]},
                        "outputs_finite": finite},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,

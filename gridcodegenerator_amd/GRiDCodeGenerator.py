@@ -9,11 +9,20 @@ one-block-per-configuration CUDA.
 
 Generation-time knobs that have no reference counterpart are keyword-only:
     precision        "fp32" | "fp64"  compute type C used for T=float (I/O stays T)
-    trig             "f32" | "f64"    sin/cos in float, or in double then rounded as the reference does
+    trig             "fast" | "libm" | "f64"   inline float sincos (default), library sincosf, or double then rounded
+                                      as the reference does (helpers/_topology_helpers.py:127-128)
     suggested_threads                 threads per block the LDS counts are sized for (multiple of 64)
     out_chunk                         max values per configuration staged in LDS per coalesced flush
     emit_order       "demand" | "creation"  ordering of the straight-line bodies
     emit_inner_api                    also emit the pointer-style ``_inner`` tier (API parity)
+    out_mode         "staged" | "direct"  LDS-staged flat stores (default) or per-lane row stores for kernel outputs.
+                                      Measured (iiwa-7 FD gradient): staged 12.5 us vs direct 15.0 us at K=16384 (split 3),
+                                      75 us vs 126 us at K=262144 -- strided 4-byte stores become the bottleneck.
+    packed                            EXPERIMENTAL: emit the (d/dq, d/dqd) gradient recursions as packed pairs
+                                      (v_pk_fma_f32).  Halves the fp instruction count (6777 -> 4818 for iiwa-7) but hipcc
+                                      allocates the 64-bit pairs badly (512 registers + spills): 29 us vs 17 us.  Off.
+    waves_per_simd                    __launch_bounds__ occupancy hint for the unsplit kernels (caps registers at 512/w)
+    grad_splits      "auto" | list    column-split variants of the two gradient kernels to emit (small-batch speed)
     fence_every                       extra scheduling fence every N emitted statements (0 = none).  A fence always
                                       follows each output store: without it hipcc's machine scheduler hoists every
                                       output's dot product above the stores (iiwa-7 FD gradient: 472 vs 257 registers)
@@ -26,12 +35,12 @@ from .helpers._text import TextMixin
 
 class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin):
     def __init__(self, robotObj, DEBUG_MODE=False, NEED_PRINT_MAT=False, USE_DYNAMIC_SHARED_MEM=True,
-                 FILE_NAMESPACE="grid", *, precision="fp32", trig="f32", suggested_threads=64, max_threads=256,
-                 out_chunk=64, emit_order="demand", emit_inner_api=True, suggested_max_blocks=2048, fence_every=0):
+                 FILE_NAMESPACE="grid", *, precision="fp32", trig="fast", suggested_threads=64, max_threads=256,
+                 out_chunk=64, emit_order="demand", emit_inner_api=True, suggested_max_blocks=2048, fence_every=0, grad_splits="auto", out_mode="staged", packed=False, waves_per_simd=1):
         if precision not in ("fp32", "fp64"):
             raise ValueError("precision must be 'fp32' or 'fp64'")
-        if trig not in ("f32", "f64"):
-            raise ValueError("trig must be 'f32' or 'f64'")
+        if trig not in ("fast", "libm", "f64"):
+            raise ValueError("trig must be 'fast', 'libm' or 'f64'")
         if suggested_threads % 64 != 0 or not (64 <= suggested_threads <= max_threads <= 1024):
             raise ValueError("need 64 <= suggested_threads <= max_threads <= 1024, suggested_threads a multiple of 64")
         self.robot = robotObj
@@ -51,6 +60,14 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin):
         self.out_chunk = int(out_chunk)
         self.emit_order = emit_order
         self.fence_every = int(fence_every)
+        self.grad_splits = grad_splits
+        if out_mode not in ("direct", "staged"):
+            raise ValueError("out_mode must be 'direct' or 'staged'")
+        self.out_mode = out_mode
+        self.packed = bool(packed)
+        self.waves_per_simd = int(waves_per_simd)
+        self.kernel_instances = []
+        self.split_stats = {}
         self.emit_inner_api = bool(emit_inner_api)
         self.core_stats = {}
         self.trace_stats = {}
@@ -68,6 +85,19 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin):
         return (t["dva_cols_per_partial"], t["dva_cols_per_jid"], t["running_sum_dva_cols_per_jid"],
                 t["df_cols_per_partial"], t["df_cols_per_jid"], t["running_sum_df_cols_per_jid"], t["df_col_that_is_jid"])
 
+    def gen_kernel_instance_list(self):
+        """Macros that let a build instantiate ONE kernel per translation unit (parallel compiles):
+        GRID_KERNEL_INST_<k>(KW) expands to `KW <kernel specialisation k for T = float>;` with KW = `template` or
+        `extern template`.  Requires `typedef float T;` at the point of use."""
+        ns = self.file_namespace
+        self.gen_add_code_line("")
+        self.gen_add_code_line("// ---- explicit-instantiation list (T = float) for one-kernel-per-translation-unit builds ----")
+        self.gen_add_code_line("#define GRID_NUM_KERNEL_INSTANCES %d" % len(self.kernel_instances))
+        for k, decl in enumerate(self.kernel_instances):
+            self.gen_add_code_line("#define GRID_KERNEL_INST_%d(KW) KW %s" % (k, decl.replace("@NS", ns)))
+        self.gen_add_code_line("#define GRID_FOR_EACH_KERNEL_INST(KW) " + " ".join("GRID_KERNEL_INST_%d(KW)" % k
+                                                                                   for k in range(len(self.kernel_instances))))
+
     def output_file_name(self):
         return self.file_namespace + ".hip.h"
 
@@ -79,8 +109,12 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin):
             raise NotImplementedError("include_base_inertia adds data no reference emitter reads (helpers/_topology_helpers.py:5-12)")
         self._chunks = []
         self.indent_level = 0
+        from .emit.trace import Tracer
+        Tracer.use_packed = self.packed
         self.core_stats = {}
         self.trace_stats = {}
+        self.kernel_instances = []
+        self.split_stats = {}
         n = self.spec.n
         file_notes = [
             "Interface is:",
@@ -150,5 +184,6 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin):
         self.gen_forward_dynamics_gradient(use_thread_group)
         self.gen_init_close_grid()
         self.gen_add_end_control_flow()
+        self.gen_kernel_instance_list()
         with open(self.output_file_name(), "w") as fh:
             fh.write(self.code_str)

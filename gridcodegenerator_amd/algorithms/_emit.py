@@ -10,7 +10,7 @@ coalesced staging (helpers/_runtime_emit.py) and a grid-stride loop over 64-conf
 """
 from ..emit import cores
 
-MAX_IN_PIECE = 63   # inputs wider than this are staged through LDS in pieces (keeps LDS/wave small)
+MAX_IN_PIECE = 64   # inputs wider than this are staged through LDS in pieces (keeps LDS/wave small)
 
 
 def _largest_divisor_leq(n, cap):
@@ -54,6 +54,7 @@ class AlgorithmEmitMixin:
         self.gen_add_code_line(template)
         self.gen_add_code_line(qualifiers)
         self.gen_add_code_line(signature + " {", True)
+        self.gen_add_code_line("typedef C C2 __attribute__((ext_vector_type(2)));   // packed pair (d/dq, d/dqd): v_pk_* on gfx950")
         ind = "    " * self.indent_level
         lines = tracer.emit(indent=ind, order=self.emit_order, store=store, fence_every=self.fence_every)
         self.gen_add_raw("\n".join(lines))
@@ -76,19 +77,27 @@ class AlgorithmEmitMixin:
         off = 0
         while off < total:
             p = min(MAX_IN_PIECE, total - off)
-            self.gen_add_code_line("grid_load_tile<T,%d,%d>(%s + %d, %s + %d, %s, k0, it, NUM_TIMESTEPS, s_wave);"
-                                   % (p, self._pad(p), dst, off, src, off, stride))
+            self.gen_add_code_line("grid_load_tile<T,%d>(%s + %d, %s + %d, %s, k0, it, NUM_TIMESTEPS, s_wave);"
+                                   % (p, dst, off, src, off, stride))
             off += p
 
-    def _emit_kernel(self, alg, name, core, doc, out_name, primary, extras, has_gravity, accessor):
-        """primary = (buffer name, count, stride variable); extras = [(buffer name, count)] with row stride = count."""
+    def _chunk_for(self, length):
+        return length if length <= self.out_chunk else _largest_divisor_leq(length, self.out_chunk)
+
+    def _emit_kernel(self, alg, name, core, doc, out_name, primary, extras, has_gravity, accessor, parts=None):
+        """primary = (buffer name, count, stride variable); extras = [(buffer name, count)] with row stride = count.
+        parts = None: one core writes the whole row.  parts = [(core_name, cols), ...]: column-split kernel, block b
+        runs part b % len(parts) on tile group b / len(parts)."""
+        n = self.spec.n
         n_out = self.io_layout[alg]["n_out"]
-        ch = self.io_layout[alg]["chunk"]
         pname, pcount, pstride = primary
         sig = "void %s(T *d_%s, const T *d_%s, const int %s, " % (name, out_name, pname, pstride)
         for (ename, _) in extras:
             sig += "const T *d_%s, " % ename
         sig += "const robotModel<T> *d_robotModel, " + ("const T gravity, " if has_gravity else "") + "const int NUM_TIMESTEPS)"
+        self.kernel_instances.append("__global__ void @NS::%s<T>(%s);" % (
+            name, ", ".join(["T *", "const T *", "const int"] + ["const T *"] * len(extras) + ["const @NS::robotModel<T> *"]
+                            + (["const T"] if has_gravity else []) + ["const int"])))
         params = ["d_%s is the output buffer, %d values per configuration" % (out_name, n_out),
                   "d_%s is the input buffer, %d values read per configuration" % (pname, pcount),
                   "%s is the stride between configurations in d_%s" % (pstride, pname)]
@@ -97,16 +106,23 @@ class AlgorithmEmitMixin:
         if has_gravity:
             params.append("gravity is the gravity constant")
         params.append("NUM_TIMESTEPS is the number of configurations")
-        self.gen_add_func_doc(doc, ["lane-per-configuration: each wavefront owns 64 consecutive configurations per tile",
-                                    "launch with <<<blocks, SUGGESTED_THREADS, %s_DYNAMIC_SHARED_MEM_COUNT*sizeof(T)>>>; any block shape up to"
-                                    % alg, "GRID_MAX_THREADS threads is accepted (the dynamic LDS must cover ceil(threads/64) wave regions)"],
-                              params, None)
+        notes = ["lane-per-configuration: each wavefront owns 64 consecutive configurations per tile",
+                 "launch with <<<blocks, SUGGESTED_THREADS, %s_DYNAMIC_SHARED_MEM_COUNT*sizeof(T)>>>; any block shape up to" % alg,
+                 "GRID_MAX_THREADS threads is accepted (the dynamic LDS must cover ceil(threads/64) wave regions)"]
+        if parts:
+            notes += ["COLUMN-SPLIT variant for small batches: %d column groups %s; block b computes group b %% %d for tile group b / %d,"
+                      % (len(parts), [(c[0], c[-1]) for (_, c) in parts], len(parts), len(parts)),
+                      "every group repeats the shared prefix (X(q), Minv, RNEA) -- the SIMDs it uses would otherwise idle.",
+                      "gridDim must be a multiple of %d (use the *_split_launch helper)" % len(parts)]
+        self.gen_add_func_doc(doc, notes, params, None)
         self.gen_add_code_line("template <typename T, typename C = typename grid_compute<T>::type>")
-        self.gen_add_code_line("__global__ __launch_bounds__(GRID_MAX_THREADS)")
+        # split kernels exist to put >= 2 waves on a SIMD: cap them at 256 registers (2nd argument = waves per SIMD)
+        occ = 2 if parts else self.waves_per_simd
+        self.gen_add_code_line("__global__ __launch_bounds__(GRID_MAX_THREADS%s)" % (", %d" % occ if occ > 1 else ""))
         self.gen_add_code_line(sig + " {", True)
         self.gen_add_code_lines([
             "extern __shared__ __align__(16) unsigned char s_grid_dyn[];",
-            "const grid_tile_iter it;",
+            "const grid_tile_iter it(NUM_TIMESTEPS%s);" % (", %d" % len(parts) if parts else ""),
             "T *s_wave = reinterpret_cast<T *>(s_grid_dyn) + it.wave_in_block*%d;" % self.lds_per_wave(alg),
             "for (int k0 = it.k0_first; k0 < NUM_TIMESTEPS; k0 += it.k0_step){",
         ])
@@ -117,9 +133,105 @@ class AlgorithmEmitMixin:
             self.gen_add_code_line("T s_%s[%d];" % (ename, ecount))
             self._emit_load("s_" + ename, "d_" + ename, ecount, str(ecount))
         self.gen_add_code_line("const grid_in_ptrs<T> in = {%s};" % accessor)
-        self.gen_add_code_line("grid_out_staged<T,%d,%d,%d> out = {s_wave, d_%s, k0, it.lane, it.W, NUM_TIMESTEPS};"
-                               % (n_out, ch, self._pad(ch), out_name))
-        self.gen_add_code_line("%s<T,C>(in, out, %s);" % (core, "gravity" if has_gravity else "static_cast<T>(0)"))
+        grav = "gravity" if has_gravity else "static_cast<T>(0)"
+        direct = (self.out_mode == "direct")
+        if direct:
+            self.gen_add_code_line("if (k0 + it.lane < NUM_TIMESTEPS){   // staging above needed every lane; the core does not", True)
+            self.gen_add_code_line("T *d_row = d_%s + (size_t)(k0 + it.lane)*%d;" % (out_name, n_out))
+        if not parts:
+            ch = self.io_layout[alg]["chunk"]
+            if direct:
+                self.gen_add_code_line("grid_out_direct<T,0,%d,0> out = {d_row};" % n_out)
+            else:
+                self.gen_add_code_line("grid_out_staged<T,%d,%d,%d,0,%d,0> out = {s_wave, d_%s, k0, it.lane, it.W, NUM_TIMESTEPS};"
+                                       % (n_out, n_out, ch, n_out, out_name))
+            self.gen_add_code_line("%s<T,C>(in, out, %s);" % (core, grav))
+        else:
+            self.gen_add_code_line("switch (it.part){", True)
+            for pi, (pcore, cols) in enumerate(parts):
+                len0 = n * len(cols)
+                ch = self._chunk_for(len0)
+                assert 64 * ch <= self.lds_per_wave(alg)
+                self.gen_add_code_line("case %d: {" % pi, True)
+                if direct:
+                    self.gen_add_code_line("grid_out_direct<T,%d,%d,%d> out = {d_row};" % (n * cols[0], len0, n * n + n * cols[0]))
+                else:
+                    self.gen_add_code_line("grid_out_staged<T,%d,%d,%d,%d,%d,%d> out = {s_wave, d_%s, k0, it.lane, it.W, NUM_TIMESTEPS};"
+                                           % (n_out, 2 * len0, ch, n * cols[0], len0, n * n + n * cols[0], out_name))
+                self.gen_add_code_line("%s<T,C>(in, out, %s);" % (pcore, grav))
+                self.gen_add_code_line("break;")
+                self.gen_add_end_control_flow()
+            self.gen_add_code_line("default: break;")
+            self.gen_add_end_control_flow()
+        if direct:
+            self.gen_add_end_control_flow()
+        self.gen_add_end_control_flow()
+        self.gen_add_end_function()
+
+    def _choose_splits(self, builder):
+        """Column-split variants worth emitting: [(S, parts, worst part's op count)], each step improving >= 10 %."""
+        n = self.spec.n
+        if self.grad_splits == "auto":
+            cand = list(range(2, n + 1)) if n <= 8 else [2, 4, 8]
+            limit = 3 if n <= 12 else 2
+        else:
+            cand = [int(S) for S in self.grad_splits]
+            limit = len(cand)
+        base = cores._arith_ops(builder(None))
+        if not cand:
+            return base, []
+        cost = cores.range_cost_function(self.spec, builder, exact=(n <= 8))
+        picked = []
+        last = base
+        for S in cand:
+            parts, est = cores.balanced_column_split(self.spec, S, cost)
+            if len(parts) != S or any(not c for c in parts):
+                continue
+            if self.grad_splits != "auto" or est < 0.9 * last:
+                picked.append((S, parts, est))
+                last = est
+        if self.grad_splits == "auto" and len(picked) > limit:      # keep the coarsest, the finest and spread the rest
+            idx = sorted(set(round(i * (len(picked) - 1) / (limit - 1)) for i in range(limit)))
+            picked = [picked[i] for i in idx]
+        chosen = [(S, parts, max(cores._arith_ops(builder(c)) for c in parts)) for (S, parts, _) in picked]
+        return base, chosen
+
+    def _emit_split_family(self, alg, kernel_base, core_base, doc, out_name, primary, has_gravity, accessor, builder, launch_args):
+        """Cores + kernels + a launcher for the column-split variants of a gradient kernel."""
+        base, chosen = self._choose_splits(builder)
+        self.split_stats[alg] = dict(base_ops=base, splits={S: dict(parts=[(c[0], c[-1]) for c in parts], worst_ops=worst)
+                                                             for (S, parts, worst) in chosen})
+        for (S, parts, worst) in chosen:
+            named = []
+            for pi, cols in enumerate(parts):
+                cname = "%s_s%dp%d" % (core_base, S, pi)
+                self._emit_core(cname, "%s: column group %d of %d (columns %d..%d of d/dq and of d/dqd)"
+                                % (doc, pi, S, cols[0], cols[-1]), builder(cols))
+                named.append((cname, cols))
+            self._emit_kernel(alg, "%s_split%d" % (kernel_base, S), None, doc + " (column-split x%d)" % S, out_name,
+                              primary, [], has_gravity, accessor, parts=named)
+        # launcher
+        pname, pcount, pstride = primary
+        grav = "const T gravity, " if has_gravity else ""
+        self.gen_add_func_doc("Launch a column-split variant of %s (asynchronous, on `stream`)" % kernel_base,
+                              ["split must be one of %s_SPLITS; tile_blocks x split blocks of `threads` threads are launched" % alg,
+                               "returns false (and launches nothing) for an unsupported split"], [], None)
+        self.gen_add_code_line("const int %s_NUM_SPLITS = %d;" % (alg, len(chosen)))
+        self.gen_add_code_line("const int %s_SPLITS[%d] = {%s};" % (alg, max(1, len(chosen)), ",".join(str(S) for (S, _, _) in chosen) or "0"))
+        self.gen_add_code_line("const int %s_SPLIT_WORST_OPS[%d] = {%s}; // arithmetic ops of the largest part (unsplit: %d)"
+                               % (alg, max(1, len(chosen)), ",".join(str(w) for (_, _, w) in chosen) or "0", base))
+        self.gen_add_code_line("template <typename T>")
+        self.gen_add_code_line("__host__ inline")
+        self.gen_add_code_line("bool %s_split_launch(const int split, T *d_%s, const T *d_%s, const int %s, const robotModel<T> *d_robotModel, %sconst int num_timesteps,"
+                               % (kernel_base.replace("_kernel", ""), out_name, pname, pstride, grav))
+        self.gen_add_code_line("        int tile_blocks, const dim3 threads, hipStream_t stream) {", True)
+        self.gen_add_code_line("const size_t lds_bytes = grid_lds_bytes<T>(threads, %d);" % self.lds_per_wave(alg))
+        self.gen_add_code_line("if (tile_blocks < 1){tile_blocks = 1;}")
+        self.gen_add_code_line("switch (split){", True)
+        for (S, parts, worst) in chosen:
+            self.gen_add_code_line("case %d: %s_split%d<T><<<dim3(tile_blocks*%d,1,1),threads,lds_bytes,stream>>>(d_%s,d_%s,%s,d_robotModel,%snum_timesteps); return true;"
+                                   % (S, kernel_base, S, S, out_name, pname, pstride, "gravity," if has_gravity else ""))
+        self.gen_add_code_line("default: return false;")
         self.gen_add_end_control_flow()
         self.gen_add_end_function()
 
@@ -471,6 +583,11 @@ class AlgorithmEmitMixin:
         self.gen_inverse_dynamics_gradient_device(use_thread_group, True)
         self.gen_inverse_dynamics_gradient_kernel(use_thread_group, True)
         self.gen_inverse_dynamics_gradient_kernel(use_thread_group, False)
+        n = self.spec.n
+        self._emit_split_family("ID_DU", "inverse_dynamics_gradient_kernel", "inverse_dynamics_gradient_core",
+                                "Computes the gradient of inverse dynamics", "dc_du", ("q_qd", 2 * n, "stride_q_qd"), True,
+                                "s_q_qd, s_q_qd + %d, nullptr, nullptr, nullptr" % n,
+                                lambda cols: cores.core_inverse_dynamics_gradient(self.spec, False, cols), None)
         self.gen_inverse_dynamics_gradient_host()
 
     # ------------------------------------------------------------------------------------------
@@ -537,4 +654,9 @@ class AlgorithmEmitMixin:
         self.gen_forward_dynamics_gradient_device(use_thread_group, True)
         self.gen_forward_dynamics_gradient_kernel(use_thread_group, True)
         self.gen_forward_dynamics_gradient_kernel(use_thread_group, False)
+        n = self.spec.n
+        self._emit_split_family("FD_DU", "forward_dynamics_gradient_kernel", "forward_dynamics_gradient_core",
+                                "Computes the gradient of forward dynamics", "df_du", ("q_qd_u", 3 * n, "stride_q_qd_u"), True,
+                                "s_q_qd_u, s_q_qd_u + %d, s_q_qd_u + %d, nullptr, nullptr" % (n, 2 * n),
+                                lambda cols: cores.core_forward_dynamics_gradient(self.spec, False, cols), None)
         self.gen_forward_dynamics_gradient_host()

@@ -18,9 +18,7 @@ typedef float T;
 
 #ifdef GRID_EXTERN_KERNELS
 // kernels are instantiated one per translation unit (grid_kernel_inst.hip) and linked in
-#include "grid_kernel_list.inc"
-GRID_KERNEL_0(extern template) GRID_KERNEL_1(extern template) GRID_KERNEL_2(extern template) GRID_KERNEL_3(extern template)
-GRID_KERNEL_4(extern template) GRID_KERNEL_5(extern template) GRID_KERNEL_6(extern template) GRID_KERNEL_7(extern template)
+GRID_FOR_EACH_KERNEL_INST(extern template)
 #endif
 
 struct grid_handle {
@@ -29,6 +27,7 @@ struct grid_handle {
     hipStream_t *streams;
     G::gridData<T> *hd_data;
     int max_timesteps;
+    int split[5];   // per algorithm: 0 = auto, 1 = never split, S = force the S-way column-split kernel
 };
 
 static thread_local std::string g_last_error;
@@ -81,6 +80,7 @@ int grid_init(int device, grid_handle **out) {
     GRID_TRY(hipSetDevice(device), "grid_init: hipSetDevice");
     grid_handle *h = new grid_handle();
     h->device = device; h->hd_data = nullptr; h->max_timesteps = 0;
+    for (int a = 0; a < 5; a++) h->split[a] = 0;
     h->d_robotModel = G::init_robotModel<T>();
     h->streams = G::init_grid<T>();
     if (int rc = grid_check("grid_init")) { delete h; return rc; }
@@ -193,10 +193,51 @@ int grid_forward_dynamics_gradient(grid_handle *h, const float *h_q_qd_u, const 
 }
 
 // ---- device-pointer launches ------------------------------------------------------------------
+// Column-split choice (gradient kernels, default input variants only).  Splitting trades repeated prefix work (X(q), Minv,
+// RNEA) for more wavefronts.  Measured on MI355X (iiwa-7 FD gradient, tools/exp_variants.py): it pays while the batch leaves
+// CUs idle -- up to ~3 single-wave workgroups per CU (different column groups on one CU contend for instruction fetch) --
+// so pick the largest S with tiles*S <= 3 x 256.  Full chip: K=16384: 18.7 us (S=1) -> 12.5 us (S=3).
+// For batches that already fill the chip the 2-way split still wins by 5-12 % when it exists (its 256-register kernels
+// run two waves per SIMD; the unsplit kernel needs > 256 registers): K=1M: 319 us -> 285 us.
+static const int GRID_CUS = 256;   // MI355X
+static int available_splits(int alg, const int **list) {
+    if (alg == GRID_ALG_FD_DU) { *list = G::FD_DU_SPLITS; return G::FD_DU_NUM_SPLITS; }
+    if (alg == GRID_ALG_ID_DU) { *list = G::ID_DU_SPLITS; return G::ID_DU_NUM_SPLITS; }
+    *list = nullptr; return 0;
+}
+static int effective_split(const grid_handle *h, int alg, int K) {
+    const int *list; const int n = available_splits(alg, &list);
+    if (n == 0 || alg < 0 || alg > 4) return 1;
+    const int want = h->split[alg];
+    if (want == 1) return 1;
+    if (want > 1) { for (int i = 0; i < n; i++) if (list[i] == want) return want; return 1; }
+    const int tiles = (K + G::GRID_WAVE_SIZE - 1) / G::GRID_WAVE_SIZE;
+    int best = 1;
+    for (int i = 0; i < n; i++) if ((long long)tiles * list[i] <= 3LL * GRID_CUS && list[i] > best) best = list[i];
+    if (best == 1 && G::NUM_JOINTS <= 12) { for (int i = 0; i < n; i++) if (list[i] == 2) best = 2; }
+    return best;
+}
+
 static int launch_alg(grid_handle *h, int alg, float *d_out, const float *d_in, int stride, const float *d_qdd, const float *d_Minv,
                       int K, float gravity, int blocks, int threads, hipStream_t s) {
     dim3 b, t;
     launch_shape(K, blocks, threads, &b, &t);
+    if ((alg == GRID_ALG_FD_DU || alg == GRID_ALG_ID_DU) && d_qdd == nullptr && d_Minv == nullptr) {
+        const int S = effective_split(h, alg, K);
+        if (S > 1) {
+            const int nthreads = t.x * t.y * t.z;
+            int tile_blocks = (blocks > 0) ? (int)(b.x * b.y * b.z) : (K + nthreads - 1) / nthreads;
+            if (tile_blocks * S > G::SUGGESTED_MAX_BLOCKS * 4) tile_blocks = (G::SUGGESTED_MAX_BLOCKS * 4) / S;
+            bool ok = (alg == GRID_ALG_FD_DU)
+                ? G::forward_dynamics_gradient_split_launch<T>(S, d_out, d_in, stride, h->d_robotModel, gravity, K, tile_blocks, t, s)
+                : G::inverse_dynamics_gradient_split_launch<T>(S, d_out, d_in, stride, h->d_robotModel, gravity, K, tile_blocks, t, s);
+            if (ok) {
+                hipError_t e = hipGetLastError();
+                if (e != hipSuccess) { gpuAssert(e, __FILE__, __LINE__); return grid_fail("kernel launch (split)"); }
+                return 0;
+            }
+        }
+    }
     switch (alg) {
     case GRID_ALG_ID: {
         const size_t lds = G::grid_lds_bytes<T>(t, G::ID_DYNAMIC_SHARED_MEM_COUNT / (G::GRID_MAX_THREADS / G::GRID_WAVE_SIZE));
@@ -261,6 +302,27 @@ int grid_forward_dynamics_gradient_device(grid_handle *h, float *d_df_du, const 
     if (int rc = dev_prep(h, d_df_du, d_q_qd_u, K, "grid_forward_dynamics_gradient_device")) return rc;
     if ((d_qdd == nullptr) != (d_Minv == nullptr)) { g_last_error = "grid_forward_dynamics_gradient_device: pass both d_qdd and d_Minv or neither"; return -1; }
     return launch_alg(h, GRID_ALG_FD_DU, d_df_du, d_q_qd_u, stride_q_qd_u, d_qdd, d_Minv, K, gravity, blocks, threads, pick_stream(h, stream));
+}
+
+int grid_splits(int alg, int *out, int count) {
+    const int *list; const int n = available_splits(alg, &list);
+    for (int i = 0; i < n && i < count && out != nullptr; i++) out[i] = list[i];
+    return n;
+}
+int grid_set_split(grid_handle *h, int alg, int split) {
+    if (h == nullptr || alg < 0 || alg > 4 || split < 0) { g_last_error = "grid_set_split: bad arguments"; return -1; }
+    if (split > 1) {
+        const int *list; const int n = available_splits(alg, &list);
+        bool found = false;
+        for (int i = 0; i < n; i++) found = found || (list[i] == split);
+        if (!found) { g_last_error = "grid_set_split: this split was not generated for this robot/algorithm"; return -1; }
+    }
+    h->split[alg] = split;
+    return 0;
+}
+int grid_get_split(grid_handle *h, int alg, int num_timesteps) {
+    if (h == nullptr || alg < 0 || alg > 4) return -1;
+    return effective_split(h, alg, num_timesteps);
 }
 
 int grid_synchronize(grid_handle *h, void *stream) {

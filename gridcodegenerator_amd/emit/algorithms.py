@@ -15,7 +15,7 @@ reference's sparsity-compressed column storage (section 8(a) a8/a12 of SURVEY.md
 dictionaries keyed (joint, column) that only ever hold the structurally non-zero columns, and every
 6x6 product is specialised entry-by-entry by the tracer.
 """
-from .trace import V
+from .trace import P, V
 
 _I3 = range(3)
 
@@ -245,14 +245,16 @@ def fd_finish(tr, spec, Minv, u, c):
 # gradient of RNEA
 # ------------------------------------------------------------------------------------------------
 def rnea_grad(tr, spec, X, I, qd, v, a, f, gravity):
-    """dc_dq[j][col], dc_dqd[j][col] (traced scalars; structurally-zero entries are const 0).
+    """dc_du[j][col] as PAIRS (lo = d/dq, hi = d/dqd; structurally-zero entries are const 0).
 
-    v, a, f as returned by rnea() (f accumulated).  Follows _test.py:229-488 column by column;
-    only the columns (ancestors + self, then + subtree on the way back) that can be non-zero exist.
+    v, a, f as returned by rnea() (f accumulated).  Follows _test.py:229-488 column by column; only the columns
+    (ancestors + self, then + subtree on the way back) that can be non-zero exist.  The d/dq and d/dqd versions of
+    every quantity go through identical operations, so they travel as one pair (trace.P) and are emitted as
+    packed instructions.
     """
     n = spec.n
-    zero6 = zeros6(tr)
-    dv = {}; da = {}; df = {}       # (j, col) -> (dq 6-vector, dqd 6-vector)
+    zero = tr.zero()
+    dv = {}; da = {}; df = {}       # (j, col) -> 6-vector of pairs
     for j in range(n):
         p, s = spec.parent[j], spec.S_ind[j]
         if p != -1:
@@ -262,65 +264,56 @@ def rnea_grad(tr, spec, X, I, qd, v, a, f, gravity):
             Xv = None
             Xa = [X[j][r][5] * gravity for r in range(6)]
         Iv = matvec(tr, I[j], v[j])
-        cols = spec.ancestors[j] + [j]
-        for col in cols:
+        for col in spec.ancestors[j] + [j]:
             if col != j:
-                dvq = matvec(tr, X[j], dv[(p, col)][0])
-                dvqd = matvec(tr, X[j], dv[(p, col)][1])
+                dvp = matvec(tr, X[j], dv[(p, col)])
             else:
-                dvq = mxS(tr, s, Xv) if Xv is not None else list(zero6)
-                dvqd = list(zero6)
-                dvqd[s] = tr.const(1.0)
-            dv[(j, col)] = (dvq, dvqd)
-            daq = mxS(tr, s, dvq, qd[j])
-            daqd = mxS(tr, s, dvqd, qd[j])
+                seed_q = mxS(tr, s, Xv) if Xv is not None else zeros6(tr)
+                dvp = [P(tr, seed_q[r], 1.0 if r == s else 0.0) for r in range(6)]
+            dv[(j, col)] = dvp
+            dap = mxS(tr, s, dvp, qd[j])
             if col == j:
-                daq = vadd(daq, mxS(tr, s, Xa))
-                daqd = vadd(daqd, mxS(tr, s, v[j]))
+                sq, sqd = mxS(tr, s, Xa), mxS(tr, s, v[j])
+                dap = [dap[r] + P(tr, sq[r], sqd[r]) for r in range(6)]
             elif p != -1:
-                daq = matvec_acc(tr, X[j], da[(p, col)][0], daq)
-                daqd = matvec_acc(tr, X[j], da[(p, col)][1], daqd)
-            da[(j, col)] = (daq, daqd)
-            out = []
-            for (dvx, dax) in ((dvq, daq), (dvqd, daqd)):
-                # df = I da + crf(v) (I dv) + crf(dv) (I v)
-                Idv = matvec(tr, I[j], dvx)
-                t = matvec(tr, I[j], dax)
-                t = vadd(t, fxv(tr, v[j], Idv))
-                t = vadd(t, fxv(tr, dvx, Iv))
-                out.append(t)
-            df[(j, col)] = tuple(out)
-    # backward pass: df_parent[col] += X^T df_j[col] (+ X^T crf(S) f_j on the self column of dq)
+                dap = matvec_acc(tr, X[j], da[(p, col)], dap)
+            da[(j, col)] = dap
+            # df = I da + crf(v) (I dv) + crf(dv) (I v)
+            Idv = matvec(tr, I[j], dvp)
+            t = matvec(tr, I[j], dap)
+            t = vadd(t, fxv(tr, v[j], Idv))
+            t = vadd(t, fxv(tr, dvp, Iv))
+            df[(j, col)] = t
+    # backward pass: df_parent[col] += X^T df_j[col] (+ X^T crf(S) f_j on the self column of d/dq)
     for j in range(n - 1, 0, -1):
         p, s = spec.parent[j], spec.S_ind[j]
         if p == -1:
             continue
         seed = fxS(tr, s, f[j])
         for col in spec.ancestors[j] + spec.subtree[j]:
-            dq_j, dqd_j = df[(j, col)]
+            dfj = df[(j, col)]
             if col == j:
-                dq_j = vadd(dq_j, seed)
-            prev = df.get((p, col), (zero6, zero6))
-            df[(p, col)] = (mattvec_acc(tr, X[j], dq_j, prev[0]), mattvec_acc(tr, X[j], dqd_j, prev[1]))
-    dc_dq = [[tr.zero() for _ in range(n)] for _ in range(n)]
-    dc_dqd = [[tr.zero() for _ in range(n)] for _ in range(n)]
+                dfj = [dfj[r] + P(tr, seed[r], 0.0) for r in range(6)]
+            prev = df.get((p, col), [zero] * 6)
+            df[(p, col)] = mattvec_acc(tr, X[j], dfj, prev)
+    dc = [[P(tr, 0.0, 0.0) for _ in range(n)] for _ in range(n)]
     for j in range(n):
         s = spec.S_ind[j]
         for col in spec.ancestors[j] + spec.subtree[j]:
-            dc_dq[j][col] = df[(j, col)][0][s]
-            dc_dqd[j][col] = df[(j, col)][1][s]
+            e = df[(j, col)][s]
+            e = e if isinstance(e, P) else P(tr, e, e)
             if col == j and spec.damping[j] != 0.0:
-                dc_dqd[j][col] = dc_dqd[j][col] + spec.damping[j]
-    return dc_dq, dc_dqd
+                e = P(tr, e.lo, e.hi + spec.damping[j])
+            dc[j][col] = e
+    return dc
 
 
-def fd_grad_finish(tr, spec, Minv, dc_dq, dc_dqd):
-    """df_du = -Minv_sym [dc_dq | dc_dqd]  (algorithms/_forward_dynamics_gradient.py:48-57)."""
+def fd_grad_finish(tr, spec, Minv, dc, cols=None):
+    """df_du = -Minv_sym [dc_dq | dc_dqd]  (algorithms/_forward_dynamics_gradient.py:48-57) on pairs; only `cols` if given."""
     n = spec.n
-    out_q = [[None] * n for _ in range(n)]
-    out_qd = [[None] * n for _ in range(n)]
-    for col in range(n):
+    out = [[None] * n for _ in range(n)]
+    for col in (range(n) if cols is None else cols):
         for r in range(n):
-            out_q[r][col] = -tr.dot([(minv_sym(Minv, r, k), dc_dq[k][col]) for k in range(n)])
-            out_qd[r][col] = -tr.dot([(minv_sym(Minv, r, k), dc_dqd[k][col]) for k in range(n)])
-    return out_q, out_qd
+            e = -tr.dot([(minv_sym(Minv, r, k), dc[k][col]) for k in range(n)])
+            out[r][col] = e if isinstance(e, P) else P(tr, e, e)
+    return out

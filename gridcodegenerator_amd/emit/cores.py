@@ -86,25 +86,38 @@ def core_forward_dynamics(spec):
     return tr
 
 
-def _out_grad(tr, spec, dq, dqd):
+def _out_grad(tr, spec, G, cols=None):
+    """G[row][col]: pair (d/dq, d/dqd).  cols=None: all 2n^2 outputs at their global index.  cols=[c0..c1]
+    (contiguous): only those columns of both halves, at LOCAL indices 0..2*n*len(cols)-1 (d/dq columns first, then
+    d/dqd); the kernel sink maps the two local runs back to n*c0 and n*n + n*c0 (column-split kernels; dead-code
+    elimination drops everything the other columns needed)."""
     n = spec.n
-    for col in range(n):
-        for row in range(n):
-            tr.out(n * col + row, dq[row][col])
-    for col in range(n):
-        for row in range(n):
-            tr.out(n * n + n * col + row, dqd[row][col])
+    if cols is None:
+        for col in range(n):
+            for row in range(n):
+                tr.out(n * col + row, G[row][col].lo)
+        for col in range(n):
+            for row in range(n):
+                tr.out(n * n + n * col + row, G[row][col].hi)
+        return
+    assert list(cols) == list(range(cols[0], cols[-1] + 1))
+    i = 0
+    for half in ("lo", "hi"):
+        for col in cols:
+            for row in range(n):
+                tr.out(i, getattr(G[row][col], half))
+                i += 1
 
 
-def core_inverse_dynamics_gradient(spec, use_qdd):
+def core_inverse_dynamics_gradient(spec, use_qdd, cols=None):
     tr, ins, g, X, I = _setup(spec, ["q", "qd"] + (["qdd"] if use_qdd else []))
     c, v, a, f = alg.rnea(tr, spec, X, I, ins["qd"], ins.get("qdd"), g)
-    dq, dqd = alg.rnea_grad(tr, spec, X, I, ins["qd"], v, a, f, g)
-    _out_grad(tr, spec, dq, dqd)
+    dc = alg.rnea_grad(tr, spec, X, I, ins["qd"], v, a, f, g)
+    _out_grad(tr, spec, dc, cols)
     return tr
 
 
-def core_forward_dynamics_gradient(spec, use_qdd_minv):
+def core_forward_dynamics_gradient(spec, use_qdd_minv, cols=None):
     n = spec.n
     if use_qdd_minv:
         tr, ins, g, X, I = _setup(spec, ["q", "qd", "qdd"])
@@ -117,11 +130,59 @@ def core_forward_dynamics_gradient(spec, use_qdd_minv):
         c, v, a, f = alg.rnea(tr, spec, X, I, ins["qd"], None, g)
         qdd = alg.fd_finish(tr, spec, Minv, ins["u"], c)
     c, v, a, f = alg.rnea(tr, spec, X, I, ins["qd"], qdd, g)
-    dq, dqd = alg.rnea_grad(tr, spec, X, I, ins["qd"], v, a, f, g)
-    oq, oqd = alg.fd_grad_finish(tr, spec, Minv, dq, dqd)
-    _out_grad(tr, spec, oq, oqd)
+    dc = alg.rnea_grad(tr, spec, X, I, ins["qd"], v, a, f, g)
+    out = alg.fd_grad_finish(tr, spec, Minv, dc, cols)
+    _out_grad(tr, spec, out, cols)
     return tr
 
+
+def _arith_ops(tr):
+    return tr.arith_instructions()
+
+
+def range_cost_function(spec, builder, exact):
+    """cost(b, e): arithmetic ops of a part holding columns b..e-1.  exact: trace every range that is asked for
+    (small robots); otherwise a shared prefix + per-column marginal model from n single-column traces."""
+    memo = {}
+    if exact:
+        def cost(b, e):
+            if (b, e) not in memo:
+                memo[(b, e)] = _arith_ops(builder(list(range(b, e))))
+            return memo[(b, e)]
+        return cost
+    single = [_arith_ops(builder([c])) for c in range(spec.n)]
+    prefix = min(single)
+    pre = [0]
+    for x in single:
+        pre.append(pre[-1] + max(0, x - prefix))
+    return lambda b, e: prefix + pre[e] - pre[b]
+
+
+def balanced_column_split(spec, S, cost):
+    """Split columns 0..n-1 into S contiguous ranges minimising the largest part's operation count.
+    Returns (parts, ops of the largest part according to `cost`)."""
+    n = spec.n
+    S = max(1, min(S, n))
+    INF = float("inf")
+    best = [[INF] * (n + 1) for _ in range(S + 1)]
+    cut = [[0] * (n + 1) for _ in range(S + 1)]
+    best[0][0] = 0
+    for k in range(1, S + 1):
+        for e in range(k, n + 1):
+            for b in range(k - 1, e):
+                if best[k - 1][b] == INF:
+                    continue
+                c = max(best[k - 1][b], cost(b, e))
+                if c < best[k][e]:
+                    best[k][e] = c
+                    cut[k][e] = b
+    bounds = [n]
+    e = n
+    for k in range(S, 0, -1):
+        e = cut[k][e]
+        bounds.append(e)
+    bounds = bounds[::-1]
+    return [list(range(bounds[i], bounds[i + 1])) for i in range(S)], best[S][n]
 
 # ------------------------------------------------------------------------------------------------
 # pointer-style ``_inner`` bodies (API parity with the reference's ALGORITHM_inner tier)
@@ -181,11 +242,11 @@ def inner_inverse_dynamics_gradient(spec):
     v = [[tr.inp("s_vaf[%d]" % (6 * j + r)) for r in range(6)] for j in range(n)]
     a = [[tr.inp("s_vaf[%d]" % (6 * n + 6 * j + r)) for r in range(6)] for j in range(n)]
     f = [[tr.inp("s_vaf[%d]" % (12 * n + 6 * j + r)) for r in range(6)] for j in range(n)]
-    dq, dqd = alg.rnea_grad(tr, spec, X, I, ins["qd"], v, a, f, g)
+    dc = alg.rnea_grad(tr, spec, X, I, ins["qd"], v, a, f, g)
     for col in range(n):
         for row in range(n):
-            tr.out("s_dc_du[%d]" % (n * col + row), dq[row][col])
+            tr.out("s_dc_du[%d]" % (n * col + row), dc[row][col].lo)
     for col in range(n):
         for row in range(n):
-            tr.out("s_dc_du[%d]" % (n * n + n * col + row), dqd[row][col])
+            tr.out("s_dc_du[%d]" % (n * n + n * col + row), dc[row][col].hi)
     return tr

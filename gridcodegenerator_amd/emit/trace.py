@@ -46,23 +46,68 @@ class V:
         return V(self.tr, -self.ref)
 
     def __add__(self, o):
+        if isinstance(o, P):
+            return o + self
         return self.tr.add(self, self._lift(o))
 
     __radd__ = __add__
 
     def __sub__(self, o):
+        if isinstance(o, P):
+            return (-o) + self
         return self.tr.add(self, -self._lift(o))
 
     def __rsub__(self, o):
         return self.tr.add(self._lift(o), -self)
 
     def __mul__(self, o):
+        if isinstance(o, P):
+            return o * self
         return self.tr.mul(self, self._lift(o))
 
     __rmul__ = __mul__
 
     def __repr__(self):
         return "V(%r)" % (self.ref,)
+
+
+class P:
+    """A pair of traced scalars that undergo the same operations (here: the d/dq and d/dqd versions of a gradient
+    quantity).  Arithmetic on pairs is emitted as ONE packed instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32
+    on a 64-bit register pair) whenever both halves need a real operation; a lone wavefront issues a packed
+    instruction at the same cadence as a scalar one (tools/ubench/issue_rate.hip), so this halves the instruction
+    count of the gradient recursions.  Halves that fold (zeros, +-1, constants) stay scalar."""
+    __slots__ = ("tr", "lo", "hi")
+
+    def __init__(self, tr, lo, hi):
+        self.tr = tr
+        self.lo = lo if isinstance(lo, V) else V(tr, float(lo))
+        self.hi = hi if isinstance(hi, V) else V(tr, float(hi))
+
+    def is_zero(self):
+        return self.lo.is_zero() and self.hi.is_zero()
+
+    def __neg__(self):
+        return P(self.tr, -self.lo, -self.hi)
+
+    def __add__(self, o):
+        return self.tr.pair_op("add", self, o, None)
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        return self.tr.pair_op("add", self, -o if isinstance(o, (P, V)) else -float(o), None)
+
+    def __rsub__(self, o):
+        return self.tr.pair_op("add", -self, o, None)
+
+    def __mul__(self, o):
+        return self.tr.pair_op("mul", self, o, None)
+
+    __rmul__ = __mul__
+
+    def __repr__(self):
+        return "P(%r, %r)" % (self.lo.ref, self.hi.ref)
 
 
 class Tracer:
@@ -124,6 +169,9 @@ class Tracer:
         if isinstance(rb, float):
             if rb == 0.0:
                 return V(self, ra)
+            fused = self._fuse_mul_add(ra, rb)
+            if fused is not None:
+                return fused
             if ra < 0:  # -(x) + c == -(x - c)
                 return V(self, -self._node(("add", -ra, -rb, None)))
             return V(self, self._node(("add", ra, rb, None)))
@@ -131,12 +179,85 @@ class Tracer:
             return V(self, 0.0)
         if abs(ra) > abs(rb):
             ra, rb = rb, ra
+        # structural fusion: (x*y) + c becomes fma(x, y, c) whenever an operand is a product.  Decided from the
+        # expression alone (never from use counts), so every variant of a trace rounds identically; the build
+        # passes -ffp-contract=off so the compiler adds no fusions of its own.
+        fused = self._fuse_mul_add(rb, ra)
+        if fused is None:
+            fused = self._fuse_mul_add(ra, rb)
+        if fused is not None:
+            return fused
         if ra < 0:
             return V(self, -self._node(("add", -ra, -rb, None)))
         return V(self, self._node(("add", ra, rb, None)))
 
+    def _fuse_mul_add(self, rm, rc):
+        """rm: signed node ref; if it is a product node return fma(x, y, rc) (sign-correct), else None."""
+        if isinstance(rm, float):
+            return None
+        op, x, y, _ = self.nodes[abs(rm)]
+        if op != "mul":
+            return None
+        vx = V(self, x if rm > 0 else -x)
+        vy = V(self, y)
+        return self.fma(vx, vy, V(self, rc))
+
+    # --- paired (2-wide) operations ------------------------------------------------------------------
+    use_packed = True
+
+    def _halves(self, x):
+        if isinstance(x, P):
+            return x.lo, x.hi
+        if isinstance(x, V):
+            return x, x
+        v = V(self, float(x))
+        return v, v
+
+    def pair_op(self, kind, a, b, c):
+        """kind in {"fma", "mul", "add"} on operands that are P, V or numbers.  Both halves are first formed with
+        the scalar rules (all folding applies); if BOTH halves turned into brand-new arithmetic nodes, those two nodes
+        are withdrawn and replaced by one packed node."""
+        aL, aH = self._halves(a)
+        bL, bH = self._halves(b)
+        cL, cH = self._halves(c) if c is not None else (None, None)
+        mark = len(self.nodes)
+
+        def scalar(x, y, z):
+            if kind == "fma":
+                return self.fma(x, y, z)
+            if kind == "mul":
+                return self.mul(x, y)
+            return self.add(x, y)
+
+        rL = scalar(aL, bL, cL)
+        n_after_lo = len(self.nodes)
+        rH = scalar(aH, bH, cH)
+        fresh_lo = (not isinstance(rL.ref, float)) and abs(rL.ref) >= mark and abs(rL.ref) == n_after_lo - 1 and n_after_lo == mark + 1
+        fresh_hi = (not isinstance(rH.ref, float)) and abs(rH.ref) == len(self.nodes) - 1 and len(self.nodes) == n_after_lo + 1
+        if not (self.use_packed and fresh_lo and fresh_hi):
+            return P(self, rL, rH)
+        kL, kH = self.nodes[abs(rL.ref)][0], self.nodes[abs(rH.ref)][0]
+        if kL not in ("fma", "mul", "add") or kH not in ("fma", "mul", "add"):
+            return P(self, rL, rH)
+        # withdraw the two scalar nodes (they are the last two appended) and emit one packed node instead
+        for _ in range(2):
+            key = self.nodes.pop()
+            del self.cse[key]
+        if kind == "fma":
+            key = ("pkfma", (aL.ref, aH.ref), (bL.ref, bH.ref), (cL.ref, cH.ref))
+        elif kind == "mul":
+            key = ("pkmul", (aL.ref, aH.ref), (bL.ref, bH.ref), None)
+        else:
+            key = ("pkadd", (aL.ref, aH.ref), (bL.ref, bH.ref), None)
+        k = self._node(key)
+        lo = self._node(("lo", k, None, None))
+        hi = self._node(("hi", k, None, None))
+        return P(self, V(self, lo), V(self, hi))
+
     def fma(self, a, b, c):
         """a*b + c with folding."""
+        if isinstance(a, P) or isinstance(b, P) or isinstance(c, P):
+            return self.pair_op("fma", a, b, c)
         ra, rb, rc = a.ref, b.ref, c.ref
         if isinstance(rc, float) and rc == 0.0:
             return self.mul(a, b)
@@ -165,8 +286,8 @@ class Tracer:
         """sum_i a_i*b_i (+ init) as an fma chain; zero terms vanish."""
         acc = init if init is not None else V(self, 0.0)
         for (a, b) in pairs:
-            a = a if isinstance(a, V) else V(self, float(a))
-            b = b if isinstance(b, V) else V(self, float(b))
+            a = a if isinstance(a, (V, P)) else V(self, float(a))
+            b = b if isinstance(b, (V, P)) else V(self, float(b))
             acc = self.fma(a, b, acc)
         return acc
 
@@ -192,6 +313,16 @@ class Tracer:
         self.outputs.append((dst_expr, val.ref))
 
     # --- analysis / emission ---------------------------------------------------------------------
+    def _deps(self, k):
+        op, a, b, c = self.nodes[k]
+        if op == "in":
+            return ()
+        if op in ("lo", "hi"):
+            return (a,)
+        if op.startswith("pk"):
+            return tuple(abs(r) for pair in (a, b, c) if pair is not None for r in pair if not isinstance(r, float))
+        return tuple(abs(r) for r in (a, b, c) if r is not None and not isinstance(r, float))
+
     def live_nodes(self):
         live = [False] * len(self.nodes)
         stack = [abs(r) for (_, r) in self.outputs if not isinstance(r, float)]
@@ -200,12 +331,9 @@ class Tracer:
             if live[k]:
                 continue
             live[k] = True
-            op, a, b, c = self.nodes[k]
-            if op == "in":
-                continue
-            for r in (a, b, c):
-                if r is not None and not isinstance(r, float) and not live[abs(r)]:
-                    stack.append(abs(r))
+            for d in self._deps(k):
+                if not live[d]:
+                    stack.append(d)
         return live
 
     def op_counts(self):
@@ -218,7 +346,13 @@ class Tracer:
 
     def flops(self):
         c = self.op_counts()
-        return 2 * c.get("fma", 0) + c.get("mul", 0) + c.get("add", 0)
+        return (2 * c.get("fma", 0) + c.get("mul", 0) + c.get("add", 0)
+                + 4 * c.get("pkfma", 0) + 2 * c.get("pkmul", 0) + 2 * c.get("pkadd", 0))
+
+    def arith_instructions(self):
+        """Arithmetic instructions one lane issues (a packed op is one instruction)."""
+        c = self.op_counts()
+        return sum(c.get(k, 0) for k in ("fma", "mul", "add", "pkfma", "pkmul", "pkadd"))
 
     @staticmethod
     def _lit(x):
@@ -229,7 +363,20 @@ class Tracer:
     def _opnd(self, r):
         if isinstance(r, float):
             return self._lit(r)
-        return ("t%d" % r) if r > 0 else ("-t%d" % (-r))
+        op = self.nodes[abs(r)][0]
+        if op in ("lo", "hi"):
+            name = "t%d.%s" % (self.nodes[abs(r)][1], "x" if op == "lo" else "y")
+        else:
+            name = "t%d" % abs(r)
+        return name if r > 0 else "-" + name
+
+    def _pair_opnd(self, pair):
+        l, h = pair
+        if not isinstance(l, float) and not isinstance(h, float) and (l > 0) == (h > 0):
+            nl, nh = self.nodes[abs(l)], self.nodes[abs(h)]
+            if nl[0] == "lo" and nh[0] == "hi" and nl[1] == nh[1]:
+                return ("t%d" % nl[1]) if l > 0 else ("-t%d" % nl[1])
+        return "C2{%s, %s}" % (self._opnd(l), self._opnd(h))
 
     def emit(self, indent="    ", order="demand", store=None, after_store=None, fence_every=0):
         """C++ statements (compute type ``C``, storage type ``T``) for all live nodes + output stores.
@@ -265,7 +412,7 @@ class Tracer:
                 lines.append("%sconst C t%d = %s * %s;" % (indent, k, self._opnd(a), self._opnd(b)))
             elif op == "add":
                 if not isinstance(b, float) and b < 0:
-                    lines.append("%sconst C t%d = %s - t%d;" % (indent, k, self._opnd(a), -b))
+                    lines.append("%sconst C t%d = %s - %s;" % (indent, k, self._opnd(a), self._opnd(-b)))
                 elif isinstance(b, float) and b < 0:
                     lines.append("%sconst C t%d = %s - %s;" % (indent, k, self._opnd(a), self._lit(-b)))
                 else:
@@ -274,6 +421,14 @@ class Tracer:
                 lines.append("%sconst C t%d = grid_fma(%s, %s, %s);" % (indent, k, self._opnd(a), self._opnd(b), self._opnd(c)))
             elif op == "rcp":
                 lines.append("%sconst C t%d = (C)1 / %s;" % (indent, k, self._opnd(a)))
+            elif op in ("lo", "hi"):
+                count[0] -= 1       # a register half of a packed value: no instruction
+            elif op == "pkfma":
+                lines.append("%sconst C2 t%d = grid_pk_fma(%s, %s, %s);" % (indent, k, self._pair_opnd(a), self._pair_opnd(b), self._pair_opnd(c)))
+            elif op == "pkmul":
+                lines.append("%sconst C2 t%d = %s * %s;" % (indent, k, self._pair_opnd(a), self._pair_opnd(b)))
+            elif op == "pkadd":
+                lines.append("%sconst C2 t%d = %s + %s;" % (indent, k, self._pair_opnd(a), self._pair_opnd(b)))
             elif op in ("sin", "cos"):
                 pair = trig_args[a]
                 if "sin" in pair and "cos" in pair:
@@ -286,11 +441,7 @@ class Tracer:
             else:
                 raise AssertionError(op)
 
-        def deps(k):
-            op, a, b, c = self.nodes[k]
-            if op == "in":
-                return ()
-            return tuple(abs(r) for r in (a, b, c) if r is not None and not isinstance(r, float))
+        deps = self._deps
 
         if order == "creation":
             for k in range(1, len(self.nodes)):
@@ -360,6 +511,16 @@ class Tracer:
                 val[k] = rnd(get(a) * get(b) + get(c))
             elif op == "rcp":
                 val[k] = rnd(1.0 / get(a))
+            elif op == "pkfma":
+                val[k] = (rnd(get(a[0]) * get(b[0]) + get(c[0])), rnd(get(a[1]) * get(b[1]) + get(c[1])))
+            elif op == "pkmul":
+                val[k] = (rnd(get(a[0]) * get(b[0])), rnd(get(a[1]) * get(b[1])))
+            elif op == "pkadd":
+                val[k] = (rnd(get(a[0]) + get(b[0])), rnd(get(a[1]) + get(b[1])))
+            elif op == "lo":
+                val[k] = val[a][0]
+            elif op == "hi":
+                val[k] = val[a][1]
             elif op == "sin":
                 val[k] = rnd(np.sin(get(a)))
             elif op == "cos":

@@ -86,8 +86,8 @@ class RuntimeEmitMixin:
     def lds_per_wave(self, alg):
         """LDS elements one wavefront needs for algorithm ``alg`` (input staging vs output chunk)."""
         lay = self.io_layout[alg]
-        need = [WAVE * self._pad(nin) for (_, nin) in lay["inputs"]]
-        need.append(WAVE * self._pad(lay["chunk"]))
+        need = [WAVE * nin for (_, nin) in lay["inputs"]]
+        need.append(WAVE * lay["chunk"])
         return max(need)
 
     @staticmethod
@@ -160,15 +160,34 @@ class RuntimeEmitMixin:
             "template <> struct grid_compute<float> {typedef %s type;};" % compute_f,
             "__host__ __device__ __forceinline__ float grid_fma(float a, float b, float c){return __builtin_fmaf(a,b,c);}",
             "__host__ __device__ __forceinline__ double grid_fma(double a, double b, double c){return __builtin_fma(a,b,c);}",
+            "template <typename V2> __host__ __device__ __forceinline__ V2 grid_pk_fma(V2 a, V2 b, V2 c){return __builtin_elementwise_fma(a, b, c);}",
         ])
         if self.trig == "f64":
             self.gen_add_code_lines([
                 "// sin/cos evaluated in double then rounded, as the reference does (helpers/_topology_helpers.py:127-128)",
                 "__host__ __device__ __forceinline__ void grid_sincos(float x, float *s, float *c){double sd, cd; sincos((double)x, &sd, &cd); *s = (float)sd; *c = (float)cd;}",
             ])
-        else:
+        elif self.trig == "libm":
             self.gen_add_code_lines([
                 "__host__ __device__ __forceinline__ void grid_sincos(float x, float *s, float *c){sincosf(x, s, c);}",
+            ])
+        else:
+            self.gen_add_code_lines([
+                "// ~25 instructions instead of ~100 for the library sincosf: 3-term Cody-Waite reduction by pi/2 (exact with fma)",
+                "// + Cephes minimax polynomials on [-pi/4, pi/4]; max abs error 9.3e-8 for |x| <= 1e5 (library: 7e-8); larger",
+                "// arguments (never a joint angle) take the library path",
+                "__host__ __device__ __forceinline__ void grid_sincos(float x, float *s, float *c){",
+                "    if (__builtin_expect(!(__builtin_fabsf(x) <= 1.0e5f), 0)){sincosf(x, s, c); return;}",
+                "    const float k = __builtin_rintf(x*0.636619772367581343f);",
+                "    float r = __builtin_fmaf(-k, 1.5707963705062866f, x); r = __builtin_fmaf(-k, -4.371138828673793e-08f, r); r = __builtin_fmaf(-k, -1.7763568394002505e-15f, r);",
+                "    const float z = r*r;",
+                "    float sp = __builtin_fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f); sp = __builtin_fmaf(sp, z, -1.6666654611e-1f); sp = __builtin_fmaf(sp*z, r, r);",
+                "    float cp = __builtin_fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f); cp = __builtin_fmaf(cp, z, 4.166664568298827e-2f);",
+                "    cp = __builtin_fmaf(cp*z, z, __builtin_fmaf(z, -0.5f, 1.0f));",
+                "    const int q = (int)k;",
+                "    const float ss = (q & 1) ? cp : sp; const float cc = (q & 1) ? sp : cp;",
+                "    *s = (q & 2) ? -ss : ss; *c = ((q + 1) & 2) ? -cc : cc;",
+                "}",
             ])
         self.gen_add_code_lines([
             "__host__ __device__ __forceinline__ void grid_sincos(double x, double *s, double *c){sincos(x, s, c);}",
@@ -195,50 +214,77 @@ class RuntimeEmitMixin:
             "",
             "// ---- wave-level staging: W lanes <-> W consecutive configurations (W = 64 for whole waves), no block barrier ----",
             "__device__ __forceinline__ void grid_wave_sync(){",
-            "    // orders this wave's LDS writes before its LDS reads across lanes.  Workgroup scope (not wavefront) on purpose:",
-            "    // if the compiler ever turns an LDS access into a FLAT one, FLAT and DS operations of one wave may complete",
-            "    // out of order, and only the workgroup-scope fence makes it wait for both counters.",
-            "    __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"workgroup\");",
+            "    // Orders this wave's LDS writes before its LDS reads across lanes.  DS operations of one wave execute in",
+            "    // order, so hardware needs nothing beyond lgkmcnt(0); the wavefront-scope fences + wave_barrier keep the",
+            "    // compiler from moving LDS accesses across.  Deliberately NOT a workgroup-scope fence: that adds",
+            "    // s_waitcnt vmcnt(0), i.e. a full drain of the previous chunk's global stores (~1-2 us) at every chunk",
+            "    // (measured: SQ_WAIT_ANY was 40-50 % of the wave's life).  All LDS traffic here is DS (no FLAT) by construction.",
+            "    __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\");",
+            "    asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");",
             "    __builtin_amdgcn_wave_barrier();",
-            "    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"workgroup\");",
+            "    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");",
             "}",
             "/** Wave/tile bookkeeping shared by every kernel (flat thread ids; any grid/block shape up to GRID_MAX_THREADS). */",
             "struct grid_tile_iter {",
-            "    int lane; int W; int k0_first; int k0_step; int wave_in_block;",
-            "    __device__ __forceinline__ grid_tile_iter(){",
+            "    int lane; int W; int k0_first; int k0_step; int wave_in_block; int part;",
+            "    // parts > 1 (column-split kernels): blockIdx % parts selects the column group, blockIdx / parts the tiles;",
+            "    // blocks beyond the last full group of `parts` get an empty tile range",
+            "    __device__ __forceinline__ grid_tile_iter(const int NUM_TIMESTEPS, const int parts = 1){",
             "        const int nthreads = blockDim.x*blockDim.y*blockDim.z;",
             "        const int tid = threadIdx.x + blockDim.x*(threadIdx.y + blockDim.y*threadIdx.z);",
-            "        const int nblocks = gridDim.x*gridDim.y*gridDim.z;",
-            "        const int bid = blockIdx.x + gridDim.x*(blockIdx.y + gridDim.y*blockIdx.z);",
+            "        int nblocks = gridDim.x*gridDim.y*gridDim.z;",
+            "        int bid = blockIdx.x + gridDim.x*(blockIdx.y + gridDim.y*blockIdx.z);",
+            "        part = bid % parts; bid = bid / parts; nblocks = nblocks / parts;",
             "        lane = tid & (GRID_WAVE_SIZE - 1);",
             "        // wave-uniform by construction; readfirstlane tells the compiler so (SGPRs, scalar loop control)",
             "        wave_in_block = __builtin_amdgcn_readfirstlane(tid / GRID_WAVE_SIZE);",
             "        W = min(GRID_WAVE_SIZE, nthreads - wave_in_block*GRID_WAVE_SIZE); // lanes of this wave (partial last wave allowed)",
-            "        k0_first = bid*nthreads + wave_in_block*GRID_WAVE_SIZE; k0_step = nblocks*nthreads;",
+            "        k0_first = (bid < nblocks) ? bid*nthreads + wave_in_block*GRID_WAVE_SIZE : NUM_TIMESTEPS;",
+            "        k0_step = max(nblocks, 1)*nthreads;",
             "    }",
             "};",
+            "/** Opaque copy of a lane index: address arithmetic derived from it is not loop invariant, so LICM cannot hoist the",
+            " *  per-element (cfg, i) pairs of the unrolled staging loops out of the tile loop (that pinned ~N registers across",
+            " *  the whole straight-line core: Atlas RNEA went from 244 registers to 512 + 222 spills). */",
+            "__device__ __forceinline__ int grid_opaque(int x){asm volatile(\"\" : \"+v\"(x)); return x;}",
             "/**",
             " * Load N values for each of the wave's W configurations (k0 .. k0+W-1, row stride `stride`):",
-            " * flat coalesced global reads -> LDS (per-lane stride NPAD, odd => conflict free) -> lane-private registers.",
+            " * all N flat coalesced global reads are issued back to back (one memory round trip, not N/4), land in LDS at the",
+            " * flat index f = cfg*N + i, and each lane then reads its own row lane*N + i (N even => 2-way bank conflict, cheap).",
             " * Lanes past NUM_TIMESTEPS receive zeros and never store.",
             " */",
-            "template <typename T, int N, int NPAD>",
+            "template <typename T, int N>",
             "__device__ __forceinline__ void grid_load_tile(T *dst, const T *d_src, const int stride, const int k0, const grid_tile_iter &it,",
             "                                               const int NUM_TIMESTEPS, T *s_wave){",
             "    const int nvalid = min(it.W, NUM_TIMESTEPS - k0);",
-            "    const T *src = d_src + (size_t)k0*stride;",
-            "    // rolled on purpose: fully unrolled, the per-t (cfg, i) address pairs are loop invariant and get",
-            "    // hoisted out of the tile loop, pinning N extra registers across the whole straight-line core",
-            "    #pragma unroll 4",
-            "    for (int t = 0; t < N; t++){",
-            "        const int f = t*it.W + it.lane; const int cfg = f / N; const int i = f - cfg*N;",
-            "        T v = static_cast<T>(0);",
-            "        if (cfg < nvalid){v = src[(size_t)cfg*stride + i];}",
-            "        s_wave[cfg*NPAD + i] = v;",
+            "    const T *src = d_src + (size_t)k0*stride;          // wave-uniform base; per-lane offsets stay 32-bit",
+            "    const int lane = grid_opaque(it.lane);",
+            "    T tmp[N];",
+            "    if (nvalid == it.W){    // full tile (wave-uniform): no per-element predicates",
+            "        if (stride == N){   // dense rows: the wave's W*N values are one contiguous block",
+            "            #pragma unroll",
+            "            for (int t = 0; t < N; t++){tmp[t] = src[(unsigned)(t*it.W + lane)];}",
+            "        }",
+            "        else {",
+            "            #pragma unroll",
+            "            for (int t = 0; t < N; t++){",
+            "                const int f = t*it.W + lane; const int cfg = f / N; const int i = f - cfg*N;",
+            "                tmp[t] = src[(unsigned)(cfg*stride + i)];",
+            "            }",
+            "        }",
             "    }",
+            "    else {                  // ragged last tile",
+            "        #pragma unroll",
+            "        for (int t = 0; t < N; t++){",
+            "            const int f = t*it.W + lane; const int cfg = f / N; const int i = f - cfg*N;",
+            "            tmp[t] = (cfg < nvalid) ? src[(unsigned)(cfg*stride + i)] : static_cast<T>(0);",
+            "        }",
+            "    }",
+            "    #pragma unroll",
+            "    for (int t = 0; t < N; t++){s_wave[t*it.W + lane] = tmp[t];}",
             "    grid_wave_sync();",
             "    #pragma unroll",
-            "    for (int i = 0; i < N; i++){dst[i] = s_wave[it.lane*NPAD + i];}",
+            "    for (int i = 0; i < N; i++){dst[i] = s_wave[lane*N + i];}",
             "    grid_wave_sync();",
             "}",
             "/**",
@@ -246,25 +292,54 @@ class RuntimeEmitMixin:
             " * chunk is written out flat (consecutive lanes -> consecutive addresses inside each configuration's run of",
             " * CH values), so the N_OUT*W results of a wave leave as wide contiguous stores instead of W-way strided ones.",
             " */",
-            "template <typename T, int N_OUT, int CH, int CHPAD>",
+            "// ROW: values per configuration in d_dst.  The NL outputs of this sink are two runs of LEN0 values (NL = 2*LEN0) that",
+            "// start at BASE0 and BASE1 of the row (column-split kernels: some d/dq columns and the same d/dqd columns), or one run",
+            "// (NL = LEN0, BASE0 = 0) for the whole row.  CH divides LEN0, so a chunk never straddles the two runs.",
+            "template <typename T, int ROW, int NL, int CH, int BASE0, int LEN0, int BASE1>",
             "struct grid_out_staged {",
             "    T *s_wave; T *d_dst; int k0; int lane; int W; int NUM_TIMESTEPS;",
             "    __device__ __forceinline__ void flush(const int chunk){",
-            "        const int base = chunk*CH; const int len = (N_OUT - base < CH) ? (N_OUT - base) : CH;",
+            "        const int lbase = chunk*CH; const int len = (NL - lbase < CH) ? (NL - lbase) : CH;",
+            "        const int base = (lbase < LEN0) ? (BASE0 + lbase) : (BASE1 + lbase - LEN0);",
             "        const int nvalid = min(W, NUM_TIMESTEPS - k0);",
+            "        const int ln = grid_opaque(lane);",
             "        grid_wave_sync();",
-            "        T *dst = d_dst + (size_t)k0*N_OUT + base;",
-            "        #pragma unroll 4",
-            "        for (int t = 0; t < len; t++){",
-            "            const int f = t*W + lane; const int cfg = f / len; const int i = f - cfg*len;",
-            "            if (cfg < nvalid){dst[(size_t)cfg*N_OUT + i] = s_wave[cfg*CHPAD + i];}",
+            "        T *dst = d_dst + (size_t)k0*ROW + base;           // wave-uniform base; per-lane offsets stay 32-bit",
+            "        T tmp[CH];",
+            "        #pragma unroll",
+            "        for (int t = 0; t < len; t++){tmp[t] = s_wave[t*W + ln];}      // LDS holds the chunk flat: f = cfg*len + i",
+            "        if (nvalid == W){     // full tile (wave-uniform): unpredicated stores (98 exec-mask branches cost ~10 us)",
+            "            #pragma unroll",
+            "            for (int t = 0; t < len; t++){",
+            "                const int f = t*W + ln; const int cfg = f / len; const int i = f - cfg*len;",
+            "                dst[(unsigned)(cfg*ROW + i)] = tmp[t];",
+            "            }",
+            "        }",
+            "        else {",
+            "            #pragma unroll",
+            "            for (int t = 0; t < len; t++){",
+            "                const int f = t*W + ln; const int cfg = f / len; const int i = f - cfg*len;",
+            "                if (cfg < nvalid){dst[(unsigned)(cfg*ROW + i)] = tmp[t];}",
+            "            }",
             "        }",
             "        grid_wave_sync();",
             "    }",
             "    __device__ __forceinline__ void put(const int i, const T v){",
-            "        s_wave[lane*CHPAD + (i % CH)] = v;",
-            "        if (((i + 1) % CH) == 0 || i == N_OUT - 1){flush(i / CH);}",
+            "        const int lbase = (i / CH)*CH; const int len = (NL - lbase < CH) ? (NL - lbase) : CH;",
+            "        s_wave[lane*len + (i % CH)] = v;",
+            "        if (((i + 1) % CH) == 0 || i == NL - 1){flush(i / CH);}",
             "    }",
+            "};",
+            "/**",
+            " * Direct output sink: each lane stores its own row (value i at immediate offset 4*i from the lane's row pointer).",
+            " * One instruction per value and no LDS round trip; the W-way strided stores are merged by the L2.  Measured on",
+            " * MI355X (tools/ubench/staging_floor.hip, 16384 x 98 floats): 5.8 us against 6.2-7.4 us for LDS-staged flat",
+            " * copies, whose per-element address arithmetic costs more than it saves.  Used under `if (lane is active)`.",
+            " */",
+            "template <typename T, int BASE0, int LEN0, int BASE1>",
+            "struct grid_out_direct {",
+            "    T *row;",
+            "    __device__ __forceinline__ void put(const int i, const T v){row[(i < LEN0) ? (BASE0 + i) : (BASE1 + i - LEN0)] = v;}",
             "};",
             "",
         ])

@@ -26,7 +26,6 @@ REPO_DIR = os.path.dirname(PKG_DIR)
 BUILD_DIR = os.path.join(PKG_DIR, "_build")
 CSRC = os.path.join(PKG_DIR, "csrc", "grid_capi.hip")
 KERNEL_INST_SRC = os.path.join(PKG_DIR, "csrc", "grid_kernel_inst.hip")
-NUM_KERNEL_INSTANCES = 8
 INCLUDE_DIR = os.path.join(REPO_DIR, "include")
 ARCH = "gfx950"
 
@@ -54,8 +53,7 @@ def _source_fingerprint(extra=""):
                 with open(os.path.join(root, fn), "rb") as fh:
                     h.update(fh.read())
     for fn in (os.path.join(PKG_DIR, "GRiDCodeGenerator.py"), os.path.join(PKG_DIR, "robots.py"),
-               os.path.join(PKG_DIR, "robot_model.py"), CSRC, KERNEL_INST_SRC,
-               os.path.join(PKG_DIR, "csrc", "grid_kernel_list.inc"), os.path.join(INCLUDE_DIR, "grid_capi.h")):
+               os.path.join(PKG_DIR, "robot_model.py"), CSRC, KERNEL_INST_SRC, os.path.join(INCLUDE_DIR, "grid_capi.h")):
         with open(fn, "rb") as fh:
             h.update(fh.read())
     h.update(extra.encode())
@@ -87,7 +85,7 @@ def generate_header(robot, path, namespace, **gen_kwargs):
 def build_library(robot_name, precision="fp32", force=False, verbose=False, extra_flags=(), **gen_kwargs):
     """Generate + compile the shared object for a built-in robot.  Returns the .so path."""
     p = library_paths(robot_name, precision)
-    flags = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-shared", "-std=c++17", "-I" + INCLUDE_DIR] + list(extra_flags)
+    flags = ["--offload-arch=" + ARCH, "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-I" + INCLUDE_DIR] + list(extra_flags)
     fp = _source_fingerprint(repr(sorted(gen_kwargs.items())) + precision + " ".join(flags))
     if not force and os.path.exists(p["lib"]) and os.path.exists(p["stamp"]):
         with open(p["stamp"]) as fh:
@@ -95,7 +93,7 @@ def build_library(robot_name, precision="fp32", force=False, verbose=False, extr
                 return p["lib"]
     os.makedirs(BUILD_DIR, exist_ok=True)
     ns = "grid_" + robot_name
-    generate_header(get_robot(robot_name), p["header"], ns, precision=precision, **gen_kwargs)
+    gen = generate_header(get_robot(robot_name), p["header"], ns, precision=precision, **gen_kwargs)
     # one translation unit per kernel + the C-ABI unit, compiled in parallel, then linked
     common = [_hipcc()] + [f for f in flags if f != "-shared"] + [
         "-c", "-DGRID_HEADER=\"%s\"" % p["header"], "-DGRID_NS=" + ns, "-DGRID_ROBOT_NAME=\"%s\"" % robot_name,
@@ -103,7 +101,7 @@ def build_library(robot_name, precision="fp32", force=False, verbose=False, extr
     objdir = os.path.join(BUILD_DIR, "obj_" + p["tag"])
     os.makedirs(objdir, exist_ok=True)
     jobs = [("capi", common + ["-DGRID_EXTERN_KERNELS", CSRC, "-o", os.path.join(objdir, "capi.o")])]
-    for k in range(NUM_KERNEL_INSTANCES):
+    for k in range(len(gen.kernel_instances)):
         jobs.append(("kernel%d" % k, common + ["-DGRID_INST=%d" % k, KERNEL_INST_SRC, "-o", os.path.join(objdir, "kernel%d.o" % k)]))
 
     def run(job):
@@ -161,6 +159,9 @@ CAPI_SIGNATURES = [
     ("grid_inverse_dynamics_gradient_device", ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, _vp]),
     ("grid_forward_dynamics_gradient_device", ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, _vp]),
     ("grid_synchronize", ctypes.c_int, [_vp, _vp]),
+    ("grid_splits", ctypes.c_int, [ctypes.c_int, _c_int_p, ctypes.c_int]),
+    ("grid_set_split", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
+    ("grid_get_split", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     ("grid_time_device", ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_float,
                                         ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _c_float_p]),
     ("grid_kernel_attributes", ctypes.c_int, [ctypes.c_int, ctypes.c_int, _c_int_p]),
@@ -197,6 +198,11 @@ class GridLibrary:
     def check(self, rc, what):
         if rc != 0:
             raise GridLibraryError("%s failed (code %d): %s" % (what, rc, self.last_error()))
+
+    def splits(self, alg):
+        out = (ctypes.c_int * 16)()
+        k = self.lib.grid_splits(alg, out, 16)
+        return [int(out[i]) for i in range(k)]
 
     def kernel_attributes(self, alg, variant=0):
         out = (ctypes.c_int * 4)()
@@ -323,6 +329,13 @@ class GridHandle:
                                          blocks=0, threads=0, stream=None):
         self.L.check(self.L.lib.grid_forward_dynamics_gradient_device(self._h, d_df_du, d_q_qd_u, stride, d_qdd, d_Minv, K, gravity,
                                                                       blocks, threads, stream), "grid_forward_dynamics_gradient_device")
+
+    def set_split(self, alg, split):
+        """0 = automatic (default), 1 = never split, S = force the S-way column-split kernel."""
+        self.L.check(self.L.lib.grid_set_split(self._h, alg, int(split)), "grid_set_split")
+
+    def get_split(self, alg, K):
+        return int(self.L.lib.grid_get_split(self._h, alg, int(K)))
 
     def synchronize(self, stream=None):
         self.L.check(self.L.lib.grid_synchronize(self._h, stream), "grid_synchronize")

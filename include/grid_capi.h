@@ -76,6 +76,15 @@ int grid_forward_dynamics_gradient_device(grid_handle *h, float *d_df_du, const 
                                           int num_timesteps, float gravity, int blocks, int threads, void *stream);
 int grid_synchronize(grid_handle *h, void *stream);
 
+/* ---- column-split variants of the two gradient kernels (no reference counterpart) ----
+ * For small batches the chip is under-filled with one lane per configuration; the generator therefore also emits
+ * kernels in which S blocks share a tile and each computes a group of gradient columns (repeating the common prefix).
+ * grid_splits: the S values generated for `alg` (returns their number).  grid_set_split: 0 = automatic (default),
+ * 1 = never, S = force.  grid_get_split: the S a call with `num_timesteps` would use.  Results are bit-identical. */
+int grid_splits(int alg, int *out, int count);
+int grid_set_split(grid_handle *h, int alg, int split);
+int grid_get_split(grid_handle *h, int alg, int num_timesteps);
+
 /* ---- measurement ----
  * `reps` back-to-back launches of algorithm `alg` on `stream`, bracketed by hipEvents recorded on that same stream;
  * *ms_per_launch = elapsed / reps.  (Replaces the reference's `_single_timing` clock_gettime twins,

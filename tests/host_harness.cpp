@@ -53,3 +53,4 @@ void hh_inner_chain(const float *x, float *qdd_out, float *dc_du_out, int K, flo
     delete[] XI; delete[] Minv; delete[] c; delete[] vaf;
 }
 }
+extern "C" void hh_sincos(const float *x, float *s, float *c, int K) { for (int k = 0; k < K; k++) G::grid_sincos(x[k], s + k, c + k); }

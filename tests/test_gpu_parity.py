@@ -147,6 +147,36 @@ def test_launch_shapes_agree_bitwise(handles, torch_cuda):
         assert np.array_equal(o, outs[0])
 
 
+def test_column_split_kernels_bitwise(handles, torch_cuda):
+    """The column-split variants of the two gradient kernels (S blocks share a tile, each computes a group of
+    columns) must reproduce the unsplit kernel bit for bit, for every generated S, ragged K and odd grids."""
+    from gridcodegenerator_amd import host
+    torch = torch_cuda
+    for robot in ("iiwa7", "mixed5"):
+        h = handles(robot)
+        n, K = h.n, 333
+        q, qd, u = make_inputs(n, K, 23)
+        d_in = torch.from_numpy(pack(q, qd, u)).cuda()
+        for alg, call in ((host.ALG_FD_DU, h.forward_dynamics_gradient_device), (host.ALG_ID_DU, h.inverse_dynamics_gradient_device)):
+            splits = h.L.splits(alg)
+            assert splits, "no split kernels generated"
+            h.set_split(alg, 1)
+            ref = torch.zeros((K, 2 * n * n), dtype=torch.float32, device="cuda")
+            call(ref.data_ptr(), d_in.data_ptr(), 3 * n, K)
+            h.synchronize()
+            for S in splits:
+                h.set_split(alg, S)
+                assert h.get_split(alg, K) == S
+                for (blocks, threads) in [(0, 0), (2, 64), (3, 128), (4, 32)]:
+                    out = torch.full((K, 2 * n * n), 3.25, dtype=torch.float32, device="cuda")
+                    call(out.data_ptr(), d_in.data_ptr(), 3 * n, K, blocks=blocks, threads=threads)
+                    h.synchronize()
+                    assert torch.equal(out, ref), (robot, alg, S, blocks, threads)
+            h.set_split(alg, 0)
+            assert h.get_split(alg, 64 * 4096) == (2 if 2 in splits else 1)   # full chip: only the 2-way split still pays
+            assert h.get_split(alg, 16384) == max([S for S in splits if 256 * S <= 768] or [h.get_split(alg, 64 * 4096)])
+
+
 def test_strides_and_compressed_inputs(handles, tables, torch_cuda):
     """inverse_dynamics reads [q|qd] from a 3n-stride q_qd_u buffer or a dense 2n-stride q_qd buffer
     (reference USE_COMPRESSED_MEM); direct_minv reads q with stride 3n or n."""

@@ -73,3 +73,15 @@ def test_host_compiled_header(harness, tables):
     ref_dc = O.rnea_grad(T, q64, qd64, qdd_o.astype(np.float64))
     ref_dc = np.concatenate([O.flat_colmajor(ref_dc[:, :, :n]), O.flat_colmajor(ref_dc[:, :, n:])], axis=1)
     assert relerr(dc, ref_dc)[0] < 5e-6
+
+
+def test_inline_sincos_accuracy(harness):
+    """The emitted grid_sincos (Cody-Waite + minimax) against float64 sin/cos, incl. the large-argument fallback."""
+    name, lib = harness
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-np.pi, np.pi, 200000), rng.uniform(-1e5, 1e5, 200000), rng.uniform(-1e9, 1e9, 1000),
+                        [0.0, -0.0, np.pi / 2, -np.pi / 2, np.pi, 1e-30, 3e38]]).astype(np.float32)
+    s = np.zeros_like(x); c = np.zeros_like(x)
+    lib.hh_sincos(_p(x), _p(s), _p(c), len(x))
+    x64 = x.astype(np.float64)
+    assert np.abs(s - np.sin(x64)).max() < 1.5e-7 and np.abs(c - np.cos(x64)).max() < 1.5e-7
