@@ -83,7 +83,20 @@ def generate_header(robot, path, namespace, **gen_kwargs):
 
 
 def build_library(robot_name, precision="fp32", force=False, verbose=False, extra_flags=(), **gen_kwargs):
-    """Generate + compile the shared object for a built-in robot.  Returns the .so path."""
+    """Generate + compile the shared object for a built-in robot.  Returns the .so path.
+    Safe to call from several processes at once (one rank per GPU): an exclusive file lock serialises the build and the
+    late-comers find the finished library."""
+    import fcntl
+    os.makedirs(BUILD_DIR, exist_ok=True)
+    with open(os.path.join(BUILD_DIR, ".lock_%s_%s" % (robot_name, precision)), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_library_locked(robot_name, precision, force, verbose, extra_flags, gen_kwargs)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_library_locked(robot_name, precision, force, verbose, extra_flags, gen_kwargs):
     p = library_paths(robot_name, precision)
     flags = ["--offload-arch=" + ARCH, "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-I" + INCLUDE_DIR] + list(extra_flags)
     fp = _source_fingerprint(repr(sorted(gen_kwargs.items())) + precision + " ".join(flags))
