@@ -21,6 +21,7 @@ Generation-time knobs that have no reference counterpart are keyword-only:
     packed                            EXPERIMENTAL: emit the (d/dq, d/dqd) gradient recursions as packed pairs
                                       (v_pk_fma_f32).  Halves the fp instruction count (6777 -> 4818 for iiwa-7) but hipcc
                                       allocates the 64-bit pairs badly (512 registers + spills): 29 us vs 17 us.  Off.
+    pipeline         "auto" | bool    also emit the two-pass (workspace) variants of the gradient kernels; auto: n > 12
     waves_per_simd                    __launch_bounds__ occupancy hint for the unsplit kernels (caps registers at 512/w)
     grad_splits      "auto" | list    column-split variants of the two gradient kernels to emit (small-batch speed)
     fence_every                       extra scheduling fence every N emitted statements (0 = none).  A fence always
@@ -36,7 +37,7 @@ from .helpers._text import TextMixin
 class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin):
     def __init__(self, robotObj, DEBUG_MODE=False, NEED_PRINT_MAT=False, USE_DYNAMIC_SHARED_MEM=True,
                  FILE_NAMESPACE="grid", *, precision="fp32", trig="fast", suggested_threads=64, max_threads=256,
-                 out_chunk=64, emit_order="demand", emit_inner_api=True, suggested_max_blocks=2048, fence_every=0, grad_splits="auto", out_mode="staged", packed=False, waves_per_simd=1):
+                 out_chunk=64, emit_order="demand", emit_inner_api=True, suggested_max_blocks=2048, fence_every=0, grad_splits="auto", out_mode="staged", packed=False, waves_per_simd=1, pipeline="auto"):
         if precision not in ("fp32", "fp64"):
             raise ValueError("precision must be 'fp32' or 'fp64'")
         if trig not in ("fast", "libm", "f64"):
@@ -66,6 +67,7 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin):
         self.out_mode = out_mode
         self.packed = bool(packed)
         self.waves_per_simd = int(waves_per_simd)
+        self.use_pipeline = (self.spec.n > 12) if pipeline == "auto" else bool(pipeline)
         self.kernel_instances = []
         self.split_stats = {}
         self.emit_inner_api = bool(emit_inner_api)

@@ -49,21 +49,23 @@ class AlgorithmEmitMixin:
     # ------------------------------------------------------------------------------------------
     # generic pieces
     # ------------------------------------------------------------------------------------------
-    def _emit_traced_function(self, doc, notes, params, template, qualifiers, signature, tracer, store=None):
+    def _emit_traced_function(self, doc, notes, params, template, qualifiers, signature, tracer, store=None, order=None,
+                              fence_stmt="GRID_SCHED_FENCE();"):
         self.gen_add_func_doc(doc, notes, params, None)
         self.gen_add_code_line(template)
         self.gen_add_code_line(qualifiers)
         self.gen_add_code_line(signature + " {", True)
         self.gen_add_code_line("typedef C C2 __attribute__((ext_vector_type(2)));   // packed pair (d/dq, d/dqd): v_pk_* on gfx950")
         ind = "    " * self.indent_level
-        lines = tracer.emit(indent=ind, order=self.emit_order, store=store, fence_every=self.fence_every)
+        lines = tracer.emit(indent=ind, order=order or self.emit_order, store=store, fence_every=self.fence_every, fence_stmt=fence_stmt)
         self.gen_add_raw("\n".join(lines))
         self.gen_add_end_function()
         self.trace_stats[signature.split("(")[0].split()[-1] + "/" + str(len(self.trace_stats))] = tracer.op_counts()
 
-    def _emit_core(self, name, doc, tracer):
+    def _emit_core(self, name, doc, tracer, order=None, fence_stores=True, fence_stmt="GRID_SCHED_FENCE();"):
         """template <T, C, In, Out> void name(const In &in, Out &out, const T gravity)."""
         self.core_stats[name] = dict(tracer.op_counts(), flops=tracer.flops())
+        fence = " GRID_SCHED_FENCE();" if fence_stores else ""
         self._emit_traced_function(
             doc, ["straight-line body for ONE configuration (one wavefront lane); compute type C, storage type T",
                   "in: accessor with q(i), qd(i), u(i), qdd(i), Minv(i); out: sink with put(i, value), i increasing"],
@@ -71,7 +73,7 @@ class AlgorithmEmitMixin:
             "template <typename T, typename C, typename In, typename Out>",
             "__host__ __device__ __forceinline__",
             "void %s(const In &in, Out &out, const T gravity)" % name, tracer,
-            store=lambda dst, val: "out.put(%s, (T)(%s)); GRID_SCHED_FENCE();" % (dst, val))
+            store=lambda dst, val: "out.put(%s, (T)(%s));%s" % (dst, val, fence), order=order, fence_stmt=fence_stmt)
 
     def _emit_load(self, dst, src, total, stride):
         off = 0
@@ -167,6 +169,110 @@ class AlgorithmEmitMixin:
             self.gen_add_end_control_flow()
         self.gen_add_end_control_flow()
         self.gen_add_end_function()
+
+    def _emit_pipeline_family(self, alg, base, doc, out_name, primary, has_qdd_variant):
+        """Two-pass variant of a gradient kernel for robots whose working set exceeds the register file:
+        `<base>_prep_kernel` (RNEA [+ Minv, qdd]) writes v, X a_parent, f, sin/cos [, Minv] to a tile-major SoA workspace,
+        `<base>_columns_kernel` runs the column-serial gradient (emit/algorithms.py: rnea_grad_columns) re-reading it."""
+        n = self.spec.n
+        kind = "fd" if alg == "FD_DU" else "id"
+        ws = cores.WorkspaceMap(self.spec, with_minv=(kind == "fd"))
+        self.gen_add_code_line("const int %s_WORKSPACE_COUNT = %d; // T elements per configuration of the two-pass workspace "
+                               "(allocate ceil(K/64)*64 configurations)" % (alg, ws.count))
+        n_out = self.io_layout[alg]["n_out"]
+        pname, pcount, pstride = primary
+        variants = [("", False)] + ([("_qdd", True)] if has_qdd_variant else [])
+        for (sfx, use_qdd) in variants:
+            self._emit_core("%s_prep_core%s" % (base, sfx), doc + ": pass 1 (workspace producer)",
+                            cores.core_gradient_prep(self.spec, ws, kind, use_qdd), fence_stores=False)
+        self._emit_core("%s_columns_core" % base, doc + ": pass 2 (column-serial gradient over the workspace)",
+                        cores.core_gradient_columns(self.spec, ws, kind == "fd"), order="creation",
+                        fence_stmt="GRID_SCHED_FENCE(); in.sync();")
+        # ---- kernels
+        for (sfx, use_qdd) in variants:
+            name = "%s_prep_kernel" % base
+            sig = "void %s(T *d_ws, const T *d_%s, const int %s, %sconst robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS)" % (
+                name, pname, pstride, "const T *d_qdd, " if use_qdd else "")
+            self.kernel_instances.append("__global__ void @NS::%s<T>(%s);" % (
+                name, ", ".join(["T *", "const T *", "const int"] + (["const T *"] if use_qdd else []) + ["const @NS::robotModel<T> *", "const T", "const int"])))
+            self.gen_add_func_doc(doc + " -- pass 1 of the two-pass variant", ["blocks must be whole wavefronts (threads % 64 == 0)"], [], None)
+            self.gen_add_code_line("template <typename T, typename C = typename grid_compute<T>::type>")
+            self.gen_add_code_line("__global__ __launch_bounds__(GRID_MAX_THREADS)")
+            self.gen_add_code_line(sig + " {", True)
+            self.gen_add_code_lines([
+                "extern __shared__ __align__(16) unsigned char s_grid_dyn[];",
+                "const grid_tile_iter it(NUM_TIMESTEPS);",
+                "T *s_wave = reinterpret_cast<T *>(s_grid_dyn) + it.wave_in_block*%d;" % self.lds_per_wave(alg),
+                "for (int k0 = it.k0_first; k0 < NUM_TIMESTEPS; k0 += it.k0_step){",
+            ])
+            self.indent_level += 1
+            self.gen_add_code_line("T s_%s[%d];" % (pname, pcount))
+            self._emit_load("s_" + pname, "d_" + pname, pcount, pstride)
+            if use_qdd:
+                self.gen_add_code_line("T s_qdd[%d];" % n)
+                self._emit_load("s_qdd", "d_qdd", n, str(n))
+            acc = "s_%s, s_%s + %d, %s, %s, nullptr" % (pname, pname, n, ("s_%s + %d" % (pname, 2 * n)) if kind == "fd" else "nullptr",
+                                                        "s_qdd" if use_qdd else "nullptr")
+            self.gen_add_code_line("const grid_in_ptrs<T> in = {%s};" % acc)
+            self.gen_add_code_line("grid_out_ws<T> out = {d_ws + (size_t)(k0/GRID_WAVE_SIZE)*%d*GRID_WAVE_SIZE, it.lane};" % ws.count)
+            self.gen_add_code_line("%s_prep_core%s<T,C>(in, out, gravity);" % (base, sfx))
+            self.gen_add_end_control_flow()
+            self.gen_add_end_function()
+        name = "%s_columns_kernel" % base
+        sig = "void %s(T *d_%s, const T *d_%s, const int %s, const T *d_ws, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS)" % (
+            name, out_name, pname, pstride)
+        self.kernel_instances.append("__global__ void @NS::%s<T>(T *, const T *, const int, const T *, const @NS::robotModel<T> *, const T, const int);" % name)
+        self.gen_add_func_doc(doc + " -- pass 2 of the two-pass variant", ["blocks must be whole wavefronts (threads % 64 == 0)"], [], None)
+        self.gen_add_code_line("template <typename T, typename C = typename grid_compute<T>::type>")
+        self.gen_add_code_line("__global__ __launch_bounds__(GRID_MAX_THREADS)")
+        self.gen_add_code_line(sig + " {", True)
+        self.gen_add_code_lines([
+            "extern __shared__ __align__(16) unsigned char s_grid_dyn[];",
+            "const grid_tile_iter it(NUM_TIMESTEPS);",
+            "T *s_wave = reinterpret_cast<T *>(s_grid_dyn) + it.wave_in_block*%d;" % self.lds_per_wave(alg),
+            "for (int k0 = it.k0_first; k0 < NUM_TIMESTEPS; k0 += it.k0_step){",
+        ])
+        self.indent_level += 1
+        self.gen_add_code_line("T s_q_qd[%d];" % (2 * n))
+        self._emit_load("s_q_qd", "d_" + pname, 2 * n, pstride)
+        self.gen_add_code_line("const grid_in_ws<T> in = {s_q_qd, s_q_qd + %d, d_ws + (size_t)(k0/GRID_WAVE_SIZE)*%d*GRID_WAVE_SIZE, it.lane};" % (n, ws.count))
+        ch = n
+        assert 64 * ch <= self.lds_per_wave(alg)
+        self.gen_add_code_line("grid_out_staged<T,%d,%d,%d,0,%d,0> out = {s_wave, d_%s, k0, it.lane, it.W, NUM_TIMESTEPS};"
+                               % (n_out, n_out, ch, n_out, out_name))
+        self.gen_add_code_line("%s_columns_core<T,C>(in, out, gravity);" % base)
+        self.gen_add_end_control_flow()
+        self.gen_add_end_function()
+        # ---- launcher
+        self.gen_add_func_doc("Launch the two-pass variant of %s (asynchronous, on `stream`)" % base,
+                              ["d_ws: workspace of %s_WORKSPACE_COUNT * ceil(num_timesteps/64)*64 elements" % alg,
+                               "threads is rounded up to whole wavefronts"], [], None)
+        self.gen_add_code_line("template <typename T>")
+        self.gen_add_code_line("__host__ inline")
+        self.gen_add_code_line("void %s_pipeline_launch(T *d_%s, const T *d_%s, const int %s, const T *d_qdd, T *d_ws, const robotModel<T> *d_robotModel, const T gravity,"
+                               % (base, out_name, pname, pstride))
+        self.gen_add_code_line("        const int num_timesteps, dim3 blocks, dim3 threads, hipStream_t stream) {", True)
+        self.gen_add_code_lines([
+            "int nthreads = threads.x*threads.y*threads.z; nthreads = ((nthreads + GRID_WAVE_SIZE - 1)/GRID_WAVE_SIZE)*GRID_WAVE_SIZE;",
+            "if (nthreads > GRID_MAX_THREADS){nthreads = GRID_MAX_THREADS;}",
+            "threads = dim3(nthreads,1,1); blocks = dim3(blocks.x*blocks.y*blocks.z,1,1);",
+            "const size_t lds_bytes = grid_lds_bytes<T>(threads, %d);" % self.lds_per_wave(alg),
+        ])
+        if has_qdd_variant:
+            self.gen_add_code_line("if (d_qdd != nullptr){%s_prep_kernel<T><<<blocks,threads,lds_bytes,stream>>>(d_ws,d_%s,%s,d_qdd,d_robotModel,gravity,num_timesteps);}" % (base, pname, pstride))
+            self.gen_add_code_line("else {%s_prep_kernel<T><<<blocks,threads,lds_bytes,stream>>>(d_ws,d_%s,%s,d_robotModel,gravity,num_timesteps);}" % (base, pname, pstride))
+        else:
+            self.gen_add_code_line("(void)d_qdd; %s_prep_kernel<T><<<blocks,threads,lds_bytes,stream>>>(d_ws,d_%s,%s,d_robotModel,gravity,num_timesteps);" % (base, pname, pstride))
+        self.gen_add_code_line("%s_columns_kernel<T><<<blocks,threads,lds_bytes,stream>>>(d_%s,d_%s,%s,d_ws,d_robotModel,gravity,num_timesteps);" % (base, out_name, pname, pstride))
+        self.gen_add_end_function()
+
+    def _emit_no_pipeline(self, alg, base, out_name, primary):
+        pname, pcount, pstride = primary
+        self.gen_add_code_line("const int %s_WORKSPACE_COUNT = 0; // no two-pass variant generated for this robot" % alg)
+        self.gen_add_code_line("template <typename T>")
+        self.gen_add_code_line("__host__ inline")
+        self.gen_add_code_line("void %s_pipeline_launch(T *, const T *, const int, const T *, T *, const robotModel<T> *, const T, const int, dim3, dim3, hipStream_t) {}" % base)
+        self.gen_add_code_line("")
 
     def _choose_splits(self, builder):
         """Column-split variants worth emitting: [(S, parts, worst part's op count)], each step improving >= 10 %."""
@@ -588,6 +694,11 @@ class AlgorithmEmitMixin:
                                 "Computes the gradient of inverse dynamics", "dc_du", ("q_qd", 2 * n, "stride_q_qd"), True,
                                 "s_q_qd, s_q_qd + %d, nullptr, nullptr, nullptr" % n,
                                 lambda cols: cores.core_inverse_dynamics_gradient(self.spec, False, cols), None)
+        if self.use_pipeline:
+            self._emit_pipeline_family("ID_DU", "inverse_dynamics_gradient", "Computes the gradient of inverse dynamics", "dc_du",
+                                       ("q_qd", 2 * n, "stride_q_qd"), True)
+        else:
+            self._emit_no_pipeline("ID_DU", "inverse_dynamics_gradient", "dc_du", ("q_qd", 2 * n, "stride_q_qd"))
         self.gen_inverse_dynamics_gradient_host()
 
     # ------------------------------------------------------------------------------------------
@@ -659,4 +770,9 @@ class AlgorithmEmitMixin:
                                 "Computes the gradient of forward dynamics", "df_du", ("q_qd_u", 3 * n, "stride_q_qd_u"), True,
                                 "s_q_qd_u, s_q_qd_u + %d, s_q_qd_u + %d, nullptr, nullptr" % (n, 2 * n),
                                 lambda cols: cores.core_forward_dynamics_gradient(self.spec, False, cols), None)
+        if self.use_pipeline:
+            self._emit_pipeline_family("FD_DU", "forward_dynamics_gradient", "Computes the gradient of forward dynamics", "df_du",
+                                       ("q_qd_u", 3 * n, "stride_q_qd_u"), False)
+        else:
+            self._emit_no_pipeline("FD_DU", "forward_dynamics_gradient", "df_du", ("q_qd_u", 3 * n, "stride_q_qd_u"))
         self.gen_forward_dynamics_gradient_host()

@@ -28,6 +28,8 @@ struct grid_handle {
     G::gridData<T> *hd_data;
     int max_timesteps;
     int split[5];   // per algorithm: 0 = auto, 1 = never split, S = force the S-way column-split kernel
+    int pipeline[5];   // per algorithm: 0 = auto, 1 = fused kernel only, 2 = two-pass (workspace) variant
+    T *d_workspace; size_t workspace_bytes;
 };
 
 static thread_local std::string g_last_error;
@@ -80,7 +82,8 @@ int grid_init(int device, grid_handle **out) {
     GRID_TRY(hipSetDevice(device), "grid_init: hipSetDevice");
     grid_handle *h = new grid_handle();
     h->device = device; h->hd_data = nullptr; h->max_timesteps = 0;
-    for (int a = 0; a < 5; a++) h->split[a] = 0;
+    for (int a = 0; a < 5; a++) { h->split[a] = 0; h->pipeline[a] = 0; }
+    h->d_workspace = nullptr; h->workspace_bytes = 0;
     h->d_robotModel = G::init_robotModel<T>();
     h->streams = G::init_grid<T>();
     if (int rc = grid_check("grid_init")) { delete h; return rc; }
@@ -105,6 +108,7 @@ int grid_close(grid_handle *h) {
     if (h == nullptr) return 0;
     (void)hipSetDevice(h->device);
     G::close_grid<T>(h->streams, h->d_robotModel, h->hd_data);
+    if (h->d_workspace != nullptr) (void)hipFree(h->d_workspace);
     int rc = grid_check("grid_close");
     delete h;
     return rc;
@@ -218,10 +222,36 @@ static int effective_split(const grid_handle *h, int alg, int K) {
     return best;
 }
 
+// Two-pass (workspace) variants: generated for robots whose gradient working set exceeds the register file.
+static int workspace_count(int alg) {
+    return alg == GRID_ALG_FD_DU ? G::FD_DU_WORKSPACE_COUNT : (alg == GRID_ALG_ID_DU ? G::ID_DU_WORKSPACE_COUNT : 0);
+}
+static bool use_pipeline(const grid_handle *h, int alg, const float *d_qdd, const float *d_Minv) {
+    if (alg < 0 || alg > 4 || workspace_count(alg) == 0 || d_Minv != nullptr) return false;
+    if (alg == GRID_ALG_FD_DU && d_qdd != nullptr) return false;
+    return h->pipeline[alg] != 1;      // auto: the two-pass variant wherever the generator emitted one
+}
+static int ensure_workspace(grid_handle *h, int alg, int K) {
+    const size_t need = (size_t)workspace_count(alg) * (size_t)((K + G::GRID_WAVE_SIZE - 1) / G::GRID_WAVE_SIZE) * G::GRID_WAVE_SIZE * sizeof(T);
+    if (need <= h->workspace_bytes) return 0;
+    if (h->d_workspace != nullptr) { GRID_TRY(hipDeviceSynchronize(), "workspace: sync"); GRID_TRY(hipFree(h->d_workspace), "workspace: free"); h->d_workspace = nullptr; h->workspace_bytes = 0; }
+    GRID_TRY(hipMalloc((void **)&h->d_workspace, need), "workspace: hipMalloc");
+    h->workspace_bytes = need;
+    return 0;
+}
+
 static int launch_alg(grid_handle *h, int alg, float *d_out, const float *d_in, int stride, const float *d_qdd, const float *d_Minv,
                       int K, float gravity, int blocks, int threads, hipStream_t s) {
     dim3 b, t;
     launch_shape(K, blocks, threads, &b, &t);
+    if (use_pipeline(h, alg, d_qdd, d_Minv)) {
+        if (int rc = ensure_workspace(h, alg, K)) return rc;
+        if (alg == GRID_ALG_FD_DU) G::forward_dynamics_gradient_pipeline_launch<T>(d_out, d_in, stride, nullptr, h->d_workspace, h->d_robotModel, gravity, K, b, t, s);
+        else                       G::inverse_dynamics_gradient_pipeline_launch<T>(d_out, d_in, stride, d_qdd, h->d_workspace, h->d_robotModel, gravity, K, b, t, s);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { gpuAssert(e, __FILE__, __LINE__); return grid_fail("kernel launch (two-pass)"); }
+        return 0;
+    }
     if ((alg == GRID_ALG_FD_DU || alg == GRID_ALG_ID_DU) && d_qdd == nullptr && d_Minv == nullptr) {
         const int S = effective_split(h, alg, K);
         if (S > 1) {
@@ -323,6 +353,14 @@ int grid_set_split(grid_handle *h, int alg, int split) {
 int grid_get_split(grid_handle *h, int alg, int num_timesteps) {
     if (h == nullptr || alg < 0 || alg > 4) return -1;
     return effective_split(h, alg, num_timesteps);
+}
+
+int grid_workspace_count(int alg) { return workspace_count(alg); }
+int grid_set_pipeline(grid_handle *h, int alg, int mode) {
+    if (h == nullptr || alg < 0 || alg > 4 || mode < 0 || mode > 2) { g_last_error = "grid_set_pipeline: bad arguments"; return -1; }
+    if (mode == 2 && workspace_count(alg) == 0) { g_last_error = "grid_set_pipeline: no two-pass variant was generated for this robot/algorithm"; return -1; }
+    h->pipeline[alg] = mode;
+    return 0;
 }
 
 int grid_synchronize(grid_handle *h, void *stream) {

@@ -317,3 +317,106 @@ def fd_grad_finish(tr, spec, Minv, dc, cols=None):
             e = -tr.dot([(minv_sym(Minv, r, k), dc[k][col]) for k in range(n)])
             out[r][col] = e if isinstance(e, P) else P(tr, e, e)
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# explicit column-serial schedule for large robots (creation-order emission)
+# ------------------------------------------------------------------------------------------------
+def build_X_joint(tr, spec, j, qj, trig_j):
+    """X_j(q_j) for ONE joint (rematerialised per use-scope by the column-serial schedule)."""
+    A, B, D, C = spec.Xbasis[j]
+    s, c = trig_j if trig_j is not None else (tr.zero(), tr.zero())
+    Xj = [[None] * 6 for _ in range(6)]
+    for r in range(6):
+        for col in range(6):
+            if r < 3 and col >= 3:
+                Xj[r][col] = tr.zero()
+            elif r >= 3 and col >= 3:
+                Xj[r][col] = Xj[r - 3][col - 3]
+            else:
+                Xj[r][col] = tr.dot([(float(A[r, col]), s), (float(B[r, col]), c), (float(D[r, col]), qj)],
+                                    init=tr.const(float(C[r, col])))
+    return Xj
+
+
+def minv_zero_pattern(spec):
+    """Structural zeros of the (symmetric) Minv: nz[r][k] is False when Minv[r][k] folds to 0 for every q
+    (joints in different base-rooted trees).  Found by tracing direct_minv once and looking for constant entries."""
+    from .trace import Tracer
+    t = Tracer()
+    q = [t.inp("q%d" % j) for j in range(spec.n)]
+    X = build_X(t, spec, q, trig_from_q(t, spec, q))
+    M = direct_minv(t, spec, X, build_I(t, spec))
+    n = spec.n
+    return [[not minv_sym(M, r, k).is_zero() for k in range(n)] for r in range(n)]
+
+
+def rnea_grad_columns(tr, spec, I, q, qd, trig, load_v, load_xa, load_f, emit_column, order=None):
+    """Column-serial analytical gradient of RNEA (same mathematics as rnea_grad / _test.py:229-488).
+
+    Designed for robots whose gradient working set does not fit the register file (Atlas-30: 880 live values in the
+    demand-ordered trace): v_j, X_j a_parent and the accumulated f_j are NOT kept live -- `load_*` re-reads them from a
+    workspace inside each column's scope -- X_j(q) and I_j v_j are rematerialised per column, and a column's forward /
+    backward recursion runs depth-first so only one root-to-leaf path of dv, da, df is alive.  For every column
+    `emit_column(col, dc)` receives dc = {row: (d/dq value, d/dqd value)} for the structurally non-zero rows and emits
+    whatever depends on it (the outputs, or the -Minv product of the forward-dynamics gradient).
+    """
+    n = spec.n
+    for col in (order if order is not None else range(n)):
+        mark = tr.cse_mark()
+        Xc = {}
+
+        def Xof(j):
+            if j not in Xc:
+                Xc[j] = build_X_joint(tr, spec, j, q[j], trig[j])
+            return Xc[j]
+
+        dc = {}
+
+        def visit(j, dv_p, da_p):
+            s, p = spec.S_ind[j], spec.parent[j]
+            tr.fence()                       # pin this joint's workspace loads here (see grid_in_ws::sync)
+            vj = load_v(j)
+            Iv = matvec(tr, I[j], vj)
+            if j == col:
+                if p != -1:
+                    Xv = list(vj)
+                    Xv[s] = vj[s] - qd[j]
+                    dvq = mxS(tr, s, Xv)
+                else:
+                    dvq = zeros6(tr)
+                dvqd = zeros6(tr)
+                dvqd[s] = tr.const(1.0)
+                daq = vadd(mxS(tr, s, dvq, qd[j]), mxS(tr, s, load_xa(j)))
+                daqd = vadd(mxS(tr, s, dvqd, qd[j]), mxS(tr, s, vj))
+            else:
+                X = Xof(j)
+                dvq = matvec(tr, X, dv_p[0]); dvqd = matvec(tr, X, dv_p[1])
+                daq = matvec_acc(tr, X, da_p[0], mxS(tr, s, dvq, qd[j]))
+                daqd = matvec_acc(tr, X, da_p[1], mxS(tr, s, dvqd, qd[j]))
+            dfs = []
+            for (dvx, dax) in ((dvq, daq), (dvqd, daqd)):
+                t = matvec(tr, I[j], dax)
+                t = vadd(t, fxv(tr, vj, matvec(tr, I[j], dvx)))
+                t = vadd(t, fxv(tr, dvx, Iv))
+                dfs.append(t)
+            for c in spec.children[j]:
+                dfc = visit(c, (dvq, dvqd), (daq, daqd))
+                Xch = Xof(c)
+                dfs = [mattvec_acc(tr, Xch, dfc[0], dfs[0]), mattvec_acc(tr, Xch, dfc[1], dfs[1])]
+            if j == col and p != -1:
+                dfs[0] = vadd(dfs[0], fxS(tr, s, load_f(j)))
+            dc[j] = (dfs[0][s], dfs[1][s] + spec.damping[j] if (j == col and spec.damping[j] != 0.0) else dfs[1][s])
+            return dfs
+
+        cur = visit(col, None, None)
+        c = col
+        while spec.parent[c] != -1:              # carry the column up through its ancestors
+            k = spec.parent[c]
+            Xch = Xof(c)
+            cur = [mattvec(tr, Xch, cur[0]), mattvec(tr, Xch, cur[1])]
+            dc[k] = (cur[0][spec.S_ind[k]], cur[1][spec.S_ind[k]])
+            c = k
+        emit_column(col, dc)
+        tr.fence()
+        tr.cse_release(mark)

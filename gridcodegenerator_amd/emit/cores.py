@@ -250,3 +250,110 @@ def inner_inverse_dynamics_gradient(spec):
         for row in range(n):
             tr.out("s_dc_du[%d]" % (n * n + n * col + row), dc[row][col].hi)
     return tr
+
+
+# ------------------------------------------------------------------------------------------------
+# two-pass "pipeline" cores for robots whose gradient working set exceeds the register file
+# ------------------------------------------------------------------------------------------------
+class WorkspaceMap:
+    """Slot numbering of the per-configuration workspace shared by a prep core and a columns core.
+    Layout in memory is tile-major SoA: value `slot` of lane `l` of tile `t` lives at (t*count + slot)*64 + l, so every
+    access of a wavefront is one coalesced 256-byte transaction."""
+
+    def __init__(self, spec, with_minv):
+        n = spec.n
+        self.n = n
+        self.V = 0                  # v_j            6n
+        self.XA = 6 * n             # X_j a_parent   6n
+        self.F = 12 * n             # accumulated f  6n
+        self.SC = 18 * n            # sin q, cos q   2n
+        self.count = 20 * n
+        self.minv_slot = {}
+        if with_minv:
+            nz = alg.minv_zero_pattern(spec)
+            for r in range(n):
+                for k in range(r, n):
+                    if nz[r][k]:
+                        self.minv_slot[(r, k)] = self.count
+                        self.count += 1
+
+    def minv(self, r, k):
+        return self.minv_slot.get((r, k) if r <= k else (k, r))
+
+
+def _xa_from_rnea(tr, spec, X, a, g):
+    out = []
+    for j in range(spec.n):
+        p = spec.parent[j]
+        out.append(alg.matvec(tr, X[j], a[p]) if p != -1 else [X[j][r][5] * g for r in range(6)])
+    return out
+
+
+def _out_workspace(tr, spec, ws, trig, v, xa, f, Minv=None):
+    n = spec.n
+    for j in range(n):
+        for r in range(6):
+            tr.out(ws.V + 6 * j + r, v[j][r])
+            tr.out(ws.XA + 6 * j + r, xa[j][r])
+            tr.out(ws.F + 6 * j + r, f[j][r])
+        s, c = trig[j] if trig[j] is not None else (tr.zero(), tr.const(1.0))
+        tr.out(ws.SC + j, s)
+        tr.out(ws.SC + n + j, c)
+    if Minv is not None:
+        for (r, k), slot in ws.minv_slot.items():
+            tr.out(slot, Minv[r][k])
+
+
+def core_gradient_prep(spec, ws, kind, use_qdd=False):
+    """Pass 1.  kind "id": RNEA at (q, qd[, qdd]); kind "fd": Minv, RNEA(0), qdd = Minv (u - c), RNEA(qdd).
+    Writes v, X a_parent, accumulated f, sin/cos (and the non-zero upper triangle of Minv) to the workspace."""
+    if kind == "id":
+        tr, ins, g, X, I = _setup(spec, ["q", "qd"] + (["qdd"] if use_qdd else []))
+        trig = alg.trig_from_q(tr, spec, ins["q"])
+        c, v, a, f = alg.rnea(tr, spec, X, I, ins["qd"], ins.get("qdd"), g)
+        _out_workspace(tr, spec, ws, trig, v, _xa_from_rnea(tr, spec, X, a, g), f)
+        return tr
+    tr, ins, g, X, I = _setup(spec, ["q", "qd", "u"])
+    trig = alg.trig_from_q(tr, spec, ins["q"])
+    Minv = alg.direct_minv(tr, spec, X, I)
+    c, v, a, f = alg.rnea(tr, spec, X, I, ins["qd"], None, g)
+    qdd = alg.fd_finish(tr, spec, Minv, ins["u"], c)
+    c, v, a, f = alg.rnea(tr, spec, X, I, ins["qd"], qdd, g)
+    _out_workspace(tr, spec, ws, trig, v, _xa_from_rnea(tr, spec, X, a, g), f, Minv)
+    return tr
+
+
+def core_gradient_columns(spec, ws, with_minv):
+    """Pass 2 (creation-order emission).  Column-serial gradient reading the workspace; with_minv also applies
+    df_du[:, col] = -Minv_sym dc_du[:, col] per column.  Outputs: column `col` of d/dq (indices n*col..) then of d/dqd."""
+    n = spec.n
+    tr = Tracer()
+    q = [tr.inp("in.q(%d)" % j) for j in range(n)]
+    qd = [tr.inp("in.qd(%d)" % j) for j in range(n)]
+    trig = [(tr.inp("in.ws(%d)" % (ws.SC + j)), tr.inp("in.ws(%d)" % (ws.SC + n + j))) if spec.uses_trig[j] else None
+            for j in range(n)]
+    I = alg.build_I(tr, spec)
+    load = lambda base: (lambda j: [tr.inp("in.ws(%d)" % (base + 6 * j + r)) for r in range(6)])
+
+    def emit_column(col, dc):
+        rows = sorted(dc)
+        if not with_minv:
+            for half in (0, 1):
+                for r in range(n):
+                    e = dc.get(r)
+                    tr.out(half * n * n + n * col + r, e[half] if e is not None else tr.zero())
+            return
+        # -Minv_sym dc: both halves of a row share the Minv loads; the second half waits in registers for its chunk
+        hi = []
+        tr.fence()
+        for r in range(n):
+            m = [(k, tr.inp("in.ws(%d)" % ws.minv(r, k))) for k in rows if ws.minv(r, k) is not None]
+            tr.out(n * col + r, -tr.dot([(mk, dc[k][0]) for (k, mk) in m]))
+            hi.append(-tr.dot([(mk, dc[k][1]) for (k, mk) in m]))
+            if r % 3 == 2:
+                tr.fence()
+        for r in range(n):
+            tr.out(n * n + n * col + r, hi[r])
+
+    alg.rnea_grad_columns(tr, spec, I, q, qd, trig, load(ws.V), load(ws.XA), load(ws.F), emit_column)
+    return tr

@@ -115,6 +115,8 @@ class Tracer:
         self.nodes = [None]      # 1-based; each node: (op, a, b, c) with operand refs / payload
         self.cse = {}
         self.outputs = []        # (dst_expr, ref)
+        self.out_pos = []        # node count when each output was recorded
+        self.fences = []         # node counts at which a scheduling fence was requested
         self.comments = {}       # node index -> comment emitted before it
 
     # --- leaf constructors ---------------------------------------------------------------------
@@ -311,6 +313,23 @@ class Tracer:
     def out(self, dst_expr, val):
         val = val if isinstance(val, V) else V(self, float(val))
         self.outputs.append((dst_expr, val.ref))
+        self.out_pos.append(len(self.nodes))       # creation-order emission places the store here
+
+    def fence(self):
+        """Scheduling fence at this point of the trace (creation-order emission only)."""
+        self.fences.append(len(self.nodes))
+
+    def cse_mark(self):
+        return len(self.nodes)
+
+    def cse_release(self, mark, keep=()):
+        """Forget the common-subexpression entries of every node created since `mark` (except `keep` refs): a later
+        identical expression is then RECOMPUTED (or, for an input, re-loaded) instead of extending the old value's life.
+        This is how the explicit schedules rematerialise X_j(q) entries and reload workspace values per column."""
+        keep = set(abs(r) for r in keep if not isinstance(r, float))
+        for k in range(mark, len(self.nodes)):
+            if k not in keep and self.cse.get(self.nodes[k]) == k:
+                del self.cse[self.nodes[k]]
 
     # --- analysis / emission ---------------------------------------------------------------------
     def _deps(self, k):
@@ -378,7 +397,7 @@ class Tracer:
                 return ("t%d" % nl[1]) if l > 0 else ("-t%d" % nl[1])
         return "C2{%s, %s}" % (self._opnd(l), self._opnd(h))
 
-    def emit(self, indent="    ", order="demand", store=None, after_store=None, fence_every=0):
+    def emit(self, indent="    ", order="demand", store=None, after_store=None, fence_every=0, fence_stmt="GRID_SCHED_FENCE();"):
         """C++ statements (compute type ``C``, storage type ``T``) for all live nodes + output stores.
 
         order="demand": outputs are visited in order and each pulls in (post-order) whatever it still
@@ -444,15 +463,24 @@ class Tracer:
         deps = self._deps
 
         if order == "creation":
-            for k in range(1, len(self.nodes)):
-                if live[k] and not emitted[k]:
+            # nodes in trace order; every store where the algorithm recorded it; explicit fences honoured
+            events = sorted([(pos, 0, i) for i, pos in enumerate(self.out_pos)] + [(pos, 1, -1) for pos in self.fences])
+            ev = 0
+            for k in range(1, len(self.nodes) + 1):
+                while ev < len(events) and events[ev][0] <= k:
+                    _, kind, i = events[ev]
+                    ev += 1
+                    if kind == 1:
+                        lines.append(indent + fence_stmt)
+                        continue
+                    dst, r = self.outputs[i]
+                    lines.append(indent + store(dst, self._opnd(r)))
+                    if after_store is not None:
+                        extra = after_store(i)
+                        if extra:
+                            lines.append(indent + extra)
+                if k < len(self.nodes) and live[k] and not emitted[k]:
                     emit_node(k)
-            for i, (dst, r) in enumerate(self.outputs):
-                lines.append(indent + store(dst, self._opnd(r)))
-                if after_store is not None:
-                    extra = after_store(i)
-                    if extra:
-                        lines.append(indent + extra)
             return lines
         for i, (dst, r) in enumerate(self.outputs):
             if not isinstance(r, float):

@@ -206,6 +206,22 @@ class RuntimeEmitMixin:
             "    __host__ __device__ __forceinline__ T qdd(int i) const {return qdd_[i];}",
             "    __host__ __device__ __forceinline__ T Minv(int i) const {return Minv_[i];}",
             "};",
+            "// accessors of the two-pass (pipeline) kernels: the per-tile workspace is SoA, value `slot` of lane l at slot*64 + l",
+            "template <typename T>",
+            "struct grid_in_ws {",
+            "    const T *q_; const T *qd_; const T *ws_tile_; mutable int lane_;",
+            "    // sync(): launder the lane index so that workspace loads issued after this point cannot be hoisted above it",
+            "    // (without it hipcc pulls hundreds of loads to the top of the kernel and spills: 512 registers + 2.7 KB scratch)",
+            "    __device__ __forceinline__ void sync() const {asm volatile(\"\" : \"+v\"(lane_));}",
+            "    __device__ __forceinline__ T q(int i) const {return q_[i];}",
+            "    __device__ __forceinline__ T qd(int i) const {return qd_[i];}",
+            "    __device__ __forceinline__ T ws(int slot) const {return ws_tile_[slot*GRID_WAVE_SIZE + lane_];}",
+            "};",
+            "template <typename T>",
+            "struct grid_out_ws {",
+            "    T *ws_tile_; int lane_;",
+            "    __device__ __forceinline__ void put(int slot, T v){ws_tile_[slot*GRID_WAVE_SIZE + lane_] = v;}",
+            "};",
             "template <typename T>",
             "struct grid_out_ptr {",
             "    T *p_;",

@@ -96,7 +96,13 @@ def build_library(robot_name, precision="fp32", force=False, verbose=False, extr
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
+# generator options used when a built-in robot is built without explicit options (tests rely on these)
+DEFAULT_GEN_KWARGS = {"mixed5": {"pipeline": True}}   # the small test robot also exercises the two-pass kernels
+
+
 def _build_library_locked(robot_name, precision, force, verbose, extra_flags, gen_kwargs):
+    if not gen_kwargs:
+        gen_kwargs = dict(DEFAULT_GEN_KWARGS.get(robot_name, {}))
     p = library_paths(robot_name, precision)
     flags = ["--offload-arch=" + ARCH, "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-I" + INCLUDE_DIR] + list(extra_flags)
     fp = _source_fingerprint(repr(sorted(gen_kwargs.items())) + precision + " ".join(flags))
@@ -175,6 +181,8 @@ CAPI_SIGNATURES = [
     ("grid_splits", ctypes.c_int, [ctypes.c_int, _c_int_p, ctypes.c_int]),
     ("grid_set_split", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     ("grid_get_split", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
+    ("grid_workspace_count", ctypes.c_int, [ctypes.c_int]),
+    ("grid_set_pipeline", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     ("grid_time_device", ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_float,
                                         ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _c_float_p]),
     ("grid_kernel_attributes", ctypes.c_int, [ctypes.c_int, ctypes.c_int, _c_int_p]),
@@ -346,6 +354,10 @@ class GridHandle:
     def set_split(self, alg, split):
         """0 = automatic (default), 1 = never split, S = force the S-way column-split kernel."""
         self.L.check(self.L.lib.grid_set_split(self._h, alg, int(split)), "grid_set_split")
+
+    def set_pipeline(self, alg, mode):
+        """0 = automatic, 1 = fused kernel only, 2 = two-pass (workspace) variant."""
+        self.L.check(self.L.lib.grid_set_pipeline(self._h, alg, int(mode)), "grid_set_pipeline")
 
     def get_split(self, alg, K):
         return int(self.L.lib.grid_get_split(self._h, alg, int(K)))

@@ -85,6 +85,15 @@ int grid_splits(int alg, int *out, int count);
 int grid_set_split(grid_handle *h, int alg, int split);
 int grid_get_split(grid_handle *h, int alg, int num_timesteps);
 
+/* ---- two-pass (workspace) variants of the gradient kernels (no reference counterpart) ----
+ * For robots whose gradient working set exceeds the register file (Atlas-30) the generator also emits a two-kernel
+ * variant: pass 1 (RNEA [+ Minv, qdd]) writes per-joint quantities to a tile-major SoA workspace in HBM, pass 2 runs the
+ * gradient column by column re-reading them.  grid_workspace_count: elements per configuration (0 = not generated).
+ * grid_set_pipeline: 0 = automatic (default: use it where generated), 1 = fused kernel only, 2 = two-pass.
+ * The workspace lives in the handle and grows on demand (first call at a new batch size allocates). */
+int grid_workspace_count(int alg);
+int grid_set_pipeline(grid_handle *h, int alg, int mode);
+
 /* ---- measurement ----
  * `reps` back-to-back launches of algorithm `alg` on `stream`, bracketed by hipEvents recorded on that same stream;
  * *ms_per_launch = elapsed / reps.  (Replaces the reference's `_single_timing` clock_gettime twins,

@@ -177,6 +177,48 @@ def test_column_split_kernels_bitwise(handles, torch_cuda):
             assert h.get_split(alg, 16384) == max([S for S in splits if 256 * S <= 768] or [h.get_split(alg, 64 * 4096)])
 
 
+@pytest.mark.parametrize("robot", ["mixed5", "atlas30"])
+def test_two_pass_pipeline_kernels(robot, handles, tables, torch_cuda):
+    """The two-pass (workspace) variants of the gradient kernels against the oracle and against the fused kernels
+    (same mathematics, different schedule: agreement to fp32 round-off, not bitwise), incl. a ragged tail and regrowth
+    of the workspace."""
+    from gridcodegenerator_amd import host
+    from oracle import rbd_oracle as O
+    torch = torch_cuda
+    h = handles(robot)
+    n = h.n
+    assert h.L.lib.grid_workspace_count(host.ALG_FD_DU) > 0 and h.L.lib.grid_workspace_count(host.ALG_ID_DU) > 0
+    T = tables(robot)
+    for K in (70, 333):
+        q, qd, u = make_inputs(n, K, 50 + K)
+        ref = oracle_all(T, q, qd, u)
+        d_in = torch.from_numpy(pack(q, qd, u)).cuda()
+        qdd32 = ref["qdd"].astype(np.float32)
+        d_qdd = torch.from_numpy(qdd32).cuda()
+        dc_ref = O.rnea_grad(T, q.astype(np.float64), qd.astype(np.float64), qdd32.astype(np.float64))
+        dc_ref = np.concatenate([O.flat_colmajor(dc_ref[:, :, :n]), O.flat_colmajor(dc_ref[:, :, n:])], axis=1)
+        res = {}
+        for mode in (1, 2):
+            h.set_pipeline(host.ALG_FD_DU, mode); h.set_pipeline(host.ALG_ID_DU, mode)
+            h.set_split(host.ALG_FD_DU, 1); h.set_split(host.ALG_ID_DU, 1)
+            a = torch.full((K + 2, 2 * n * n), 1.5, dtype=torch.float32, device="cuda")
+            b = torch.full((K + 2, 2 * n * n), 1.5, dtype=torch.float32, device="cuda")
+            c = torch.full((K + 2, 2 * n * n), 1.5, dtype=torch.float32, device="cuda")
+            h.forward_dynamics_gradient_device(a.data_ptr(), d_in.data_ptr(), 3 * n, K)
+            h.inverse_dynamics_gradient_device(b.data_ptr(), d_in.data_ptr(), 3 * n, K)
+            h.inverse_dynamics_gradient_device(c.data_ptr(), d_in.data_ptr(), 3 * n, K, d_qdd=d_qdd.data_ptr())
+            h.synchronize()
+            res[mode] = [x.cpu().numpy() for x in (a, b, c)]
+            for x in res[mode]:
+                assert np.all(x[K:] == 1.5)                      # rows past K untouched
+            assert relerr(res[mode][0][:K], ref["df_du"])[0] < TOL32["df_du"]
+            assert relerr(res[mode][1][:K], ref["dc_du_noqdd"])[0] < TOL32["dc_du"]
+            assert relerr(res[mode][2][:K], dc_ref)[0] < TOL32["dc_du"]
+        assert relerr(res[2][0][:K], res[1][0][:K])[0] < TOL32["df_du"]
+    for alg in (host.ALG_FD_DU, host.ALG_ID_DU):
+        h.set_pipeline(alg, 0); h.set_split(alg, 0)
+
+
 def test_strides_and_compressed_inputs(handles, tables, torch_cuda):
     """inverse_dynamics reads [q|qd] from a 3n-stride q_qd_u buffer or a dense 2n-stride q_qd buffer
     (reference USE_COMPRESSED_MEM); direct_minv reads q with stride 3n or n."""
