@@ -22,6 +22,8 @@ Generation-time knobs that have no reference counterpart are keyword-only:
                                       (v_pk_fma_f32).  Halves the fp instruction count (6777 -> 4818 for iiwa-7) but hipcc
                                       allocates the 64-bit pairs badly (512 registers + spills): 29 us vs 17 us.  Off.
     pipeline         "auto" | bool    also emit the two-pass (workspace) variants of the gradient kernels; auto: n > 12
+    grad_schedule    "auto" | "fused" | "recompute"   body of the single-kernel gradient cores: demand-ordered fused trace, or
+                     column-serial with per-column recomputation of v, a, f (no spills for large robots); auto: recompute for n > 12
     waves_per_simd                    __launch_bounds__ occupancy hint for the unsplit kernels (caps registers at 512/w)
     grad_splits      "auto" | list    column-split variants of the two gradient kernels to emit (small-batch speed)
     fence_every                       extra scheduling fence every N emitted statements (0 = none).  A fence always
@@ -37,7 +39,7 @@ from .helpers._text import TextMixin
 class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin):
     def __init__(self, robotObj, DEBUG_MODE=False, NEED_PRINT_MAT=False, USE_DYNAMIC_SHARED_MEM=True,
                  FILE_NAMESPACE="grid", *, precision="fp32", trig="fast", suggested_threads=64, max_threads=256,
-                 out_chunk=64, emit_order="demand", emit_inner_api=True, suggested_max_blocks=2048, fence_every=0, grad_splits="auto", out_mode="staged", packed=False, waves_per_simd=1, pipeline="auto"):
+                 out_chunk=64, emit_order="demand", emit_inner_api=True, suggested_max_blocks=2048, fence_every=0, grad_splits="auto", out_mode="staged", packed=False, waves_per_simd=1, pipeline="auto", grad_schedule="auto"):
         if precision not in ("fp32", "fp64"):
             raise ValueError("precision must be 'fp32' or 'fp64'")
         if trig not in ("fast", "libm", "f64"):
@@ -68,6 +70,8 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin):
         self.packed = bool(packed)
         self.waves_per_simd = int(waves_per_simd)
         self.use_pipeline = (self.spec.n > 12) if pipeline == "auto" else bool(pipeline)
+        assert grad_schedule in ("auto", "fused", "recompute")
+        self.grad_schedule = ("recompute" if self.spec.n > 12 else "fused") if grad_schedule == "auto" else grad_schedule
         self.kernel_instances = []
         self.split_stats = {}
         self.emit_inner_api = bool(emit_inner_api)

@@ -86,7 +86,7 @@ class AlgorithmEmitMixin:
     def _chunk_for(self, length):
         return length if length <= self.out_chunk else _largest_divisor_leq(length, self.out_chunk)
 
-    def _emit_kernel(self, alg, name, core, doc, out_name, primary, extras, has_gravity, accessor, parts=None):
+    def _emit_kernel(self, alg, name, core, doc, out_name, primary, extras, has_gravity, accessor, parts=None, chunk=None):
         """primary = (buffer name, count, stride variable); extras = [(buffer name, count)] with row stride = count.
         parts = None: one core writes the whole row.  parts = [(core_name, cols), ...]: column-split kernel, block b
         runs part b % len(parts) on tile group b / len(parts)."""
@@ -132,8 +132,13 @@ class AlgorithmEmitMixin:
         self.gen_add_code_line("T s_%s[%d];" % (pname, pcount))
         self._emit_load("s_" + pname, "d_" + pname, pcount, pstride)
         for (ename, ecount) in extras:
-            self.gen_add_code_line("T s_%s[%d];" % (ename, ecount))
-            self._emit_load("s_" + ename, "d_" + ename, ecount, str(ecount))
+            if ecount > MAX_IN_PIECE:
+                # large optional inputs (Minv of a 30-joint robot: 900 values) are read where they are used, straight from
+                # the lane's row in global memory: staging them would need a 3.6 KB private array per lane
+                self.gen_add_code_line("const T *s_%s = d_%s + (size_t)min(k0 + it.lane, NUM_TIMESTEPS - 1)*%d;" % (ename, ename, ecount))
+            else:
+                self.gen_add_code_line("T s_%s[%d];" % (ename, ecount))
+                self._emit_load("s_" + ename, "d_" + ename, ecount, str(ecount))
         self.gen_add_code_line("const grid_in_ptrs<T> in = {%s};" % accessor)
         grav = "gravity" if has_gravity else "static_cast<T>(0)"
         direct = (self.out_mode == "direct")
@@ -141,7 +146,8 @@ class AlgorithmEmitMixin:
             self.gen_add_code_line("if (k0 + it.lane < NUM_TIMESTEPS){   // staging above needed every lane; the core does not", True)
             self.gen_add_code_line("T *d_row = d_%s + (size_t)(k0 + it.lane)*%d;" % (out_name, n_out))
         if not parts:
-            ch = self.io_layout[alg]["chunk"]
+            ch = chunk or self.io_layout[alg]["chunk"]
+            assert 64 * ch <= self.lds_per_wave(alg)
             if direct:
                 self.gen_add_code_line("grid_out_direct<T,0,%d,0> out = {d_row};" % n_out)
             else:
@@ -278,8 +284,10 @@ class AlgorithmEmitMixin:
         """Column-split variants worth emitting: [(S, parts, worst part's op count)], each step improving >= 10 %."""
         n = self.spec.n
         if self.grad_splits == "auto":
-            cand = list(range(2, n + 1)) if n <= 8 else [2, 4, 8]
-            limit = 3 if n <= 12 else 2
+            # large robots: the split kernels need > 256 registers per column group, spill, take 10-25 minutes each to
+            # compile and were slower than the unsplit kernel (profiles/r01/sweep_atlas30_split.txt): none by default
+            cand = list(range(2, n + 1)) if n <= 8 else ([2, 4] if n <= 12 else [])
+            limit = 3
         else:
             cand = [int(S) for S in self.grad_splits]
             limit = len(cand)
@@ -296,7 +304,7 @@ class AlgorithmEmitMixin:
             if self.grad_splits != "auto" or est < 0.9 * last:
                 picked.append((S, parts, est))
                 last = est
-        if self.grad_splits == "auto" and len(picked) > limit:      # keep the coarsest, the finest and spread the rest
+        if self.grad_splits == "auto" and len(picked) > limit > 1:      # keep the coarsest, the finest and spread the rest
             idx = sorted(set(round(i * (len(picked) - 1) / (limit - 1)) for i in range(limit)))
             picked = [picked[i] for i in idx]
         chosen = [(S, parts, max(cores._arith_ops(builder(c)) for c in parts)) for (S, parts, _) in picked]
@@ -467,7 +475,8 @@ class AlgorithmEmitMixin:
         self._emit_kernel("ID", "inverse_dynamics_kernel", "inverse_dynamics_core" + ("_qdd" if use_qdd_input else ""),
                           "Compute the RNEA (Recursive Newton-Euler Algorithm)", "c", ("q_qd", 2 * n, "stride_q_qd"),
                           [("qdd", n)] if use_qdd_input else [], True,
-                          "s_q_qd, s_q_qd + %d, nullptr, %s, nullptr" % (n, "s_qdd" if use_qdd_input else "nullptr"))
+                          "s_q_qd, s_q_qd + %d, nullptr, %s, nullptr" % (n, "s_qdd" if use_qdd_input else "nullptr"),
+                          chunk=n if self.grad_schedule == "recompute" else None)
 
     def gen_inverse_dynamics_host(self, mode=0):
         def pre(mode):
@@ -658,7 +667,8 @@ class AlgorithmEmitMixin:
         self._emit_kernel("ID_DU", "inverse_dynamics_gradient_kernel", "inverse_dynamics_gradient_core" + ("_qdd" if use_qdd_input else ""),
                           "Computes the gradient of inverse dynamics", "dc_du", ("q_qd", 2 * n, "stride_q_qd"),
                           [("qdd", n)] if use_qdd_input else [], True,
-                          "s_q_qd, s_q_qd + %d, nullptr, %s, nullptr" % (n, "s_qdd" if use_qdd_input else "nullptr"))
+                          "s_q_qd, s_q_qd + %d, nullptr, %s, nullptr" % (n, "s_qdd" if use_qdd_input else "nullptr"),
+                          chunk=n if self.grad_schedule == "recompute" else None)
 
     def gen_inverse_dynamics_gradient_host(self, mode=0):
         def pre(mode):
@@ -680,9 +690,13 @@ class AlgorithmEmitMixin:
 
     def gen_inverse_dynamics_gradient(self, use_thread_group=False):
         for use_qdd in (True, False):
-            self._emit_core("inverse_dynamics_gradient_core" + ("_qdd" if use_qdd else ""),
-                            "RNEA + analytical gradient core: dc_du = [dc/dq | dc/dqd] at (q, qd%s)" % (", qdd" if use_qdd else ", 0"),
-                            cores.core_inverse_dynamics_gradient(self.spec, use_qdd))
+            doc = "RNEA + analytical gradient core: dc_du = [dc/dq | dc/dqd] at (q, qd%s)" % (", qdd" if use_qdd else ", 0")
+            if self.grad_schedule == "recompute":
+                self._emit_core("inverse_dynamics_gradient_core" + ("_qdd" if use_qdd else ""), doc + " -- column-serial, recomputing",
+                                cores.core_gradient_recompute(self.spec, "id", use_qdd=use_qdd), order="creation")
+            else:
+                self._emit_core("inverse_dynamics_gradient_core" + ("_qdd" if use_qdd else ""), doc,
+                                cores.core_inverse_dynamics_gradient(self.spec, use_qdd))
         if self.emit_inner_api:
             self.gen_inverse_dynamics_gradient_inner(use_thread_group)
         self.gen_inverse_dynamics_gradient_device(use_thread_group, False)
@@ -729,11 +743,13 @@ class AlgorithmEmitMixin:
         if use_qdd_Minv_input:
             self._emit_kernel("FD_DU", "forward_dynamics_gradient_kernel", "forward_dynamics_gradient_core_qdd_minv",
                               "Computes the gradient of forward dynamics", "df_du", ("q_qd", 2 * n, "stride_q_qd"),
-                              [("qdd", n), ("Minv", n * n)], True, "s_q_qd, s_q_qd + %d, nullptr, s_qdd, s_Minv" % n)
+                              [("qdd", n), ("Minv", n * n)], True, "s_q_qd, s_q_qd + %d, nullptr, s_qdd, s_Minv" % n,
+                              chunk=n if self.grad_schedule == "recompute" else None)
         else:
             self._emit_kernel("FD_DU", "forward_dynamics_gradient_kernel", "forward_dynamics_gradient_core",
                               "Computes the gradient of forward dynamics", "df_du", ("q_qd_u", 3 * n, "stride_q_qd_u"),
-                              [], True, "s_q_qd_u, s_q_qd_u + %d, s_q_qd_u + %d, nullptr, nullptr" % (n, 2 * n))
+                              [], True, "s_q_qd_u, s_q_qd_u + %d, s_q_qd_u + %d, nullptr, nullptr" % (n, 2 * n),
+                              chunk=n if self.grad_schedule == "recompute" else None)
 
     def gen_forward_dynamics_gradient_host(self, mode=0):
         def pre(mode):
@@ -755,12 +771,20 @@ class AlgorithmEmitMixin:
                         "template <typename T, bool USE_QDD_MINV_FLAG = false>", True, pre, launches, post, "FD_DU")
 
     def gen_forward_dynamics_gradient(self, use_thread_group=False):
-        self._emit_core("forward_dynamics_gradient_core",
-                        "Forward-dynamics gradient core (fused): Minv, RNEA(0), qdd, RNEA(qdd), dRNEA, -Minv*dc_du; out = [dqdd/dq | dqdd/dqd]",
-                        cores.core_forward_dynamics_gradient(self.spec, False))
-        self._emit_core("forward_dynamics_gradient_core_qdd_minv",
-                        "Forward-dynamics gradient core with qdd and (upper triangular) Minv supplied",
-                        cores.core_forward_dynamics_gradient(self.spec, True))
+        if self.grad_schedule == "recompute":
+            self._emit_core("forward_dynamics_gradient_core",
+                            "Forward-dynamics gradient core: Minv, RNEA(0), qdd, then column-serial dRNEA (recomputing v, a, f per column) and -Minv*dc_du",
+                            cores.core_gradient_recompute(self.spec, "fd"), order="creation")
+            self._emit_core("forward_dynamics_gradient_core_qdd_minv",
+                            "Forward-dynamics gradient core with qdd and (upper triangular) Minv supplied -- column-serial, recomputing",
+                            cores.core_gradient_recompute(self.spec, "fd", use_qdd_minv=True), order="creation")
+        else:
+            self._emit_core("forward_dynamics_gradient_core",
+                            "Forward-dynamics gradient core (fused): Minv, RNEA(0), qdd, RNEA(qdd), dRNEA, -Minv*dc_du; out = [dqdd/dq | dqdd/dqd]",
+                            cores.core_forward_dynamics_gradient(self.spec, False))
+            self._emit_core("forward_dynamics_gradient_core_qdd_minv",
+                            "Forward-dynamics gradient core with qdd and (upper triangular) Minv supplied",
+                            cores.core_forward_dynamics_gradient(self.spec, True))
         self.gen_forward_dynamics_gradient_device(use_thread_group, False)
         self.gen_forward_dynamics_gradient_device(use_thread_group, True)
         self.gen_forward_dynamics_gradient_kernel(use_thread_group, True)

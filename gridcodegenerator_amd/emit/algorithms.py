@@ -351,22 +351,45 @@ def minv_zero_pattern(spec):
     return [[not minv_sym(M, r, k).is_zero() for k in range(n)] for r in range(n)]
 
 
-def rnea_grad_columns(tr, spec, I, q, qd, trig, load_v, load_xa, load_f, emit_column, order=None):
+def rnea_grad_columns(tr, spec, I, q, qd, trig, loader, emit_column, order=None, prefetch=3, xof=None, keep=()):
     """Column-serial analytical gradient of RNEA (same mathematics as rnea_grad / _test.py:229-488).
 
     Designed for robots whose gradient working set does not fit the register file (Atlas-30: 880 live values in the
-    demand-ordered trace): v_j, X_j a_parent and the accumulated f_j are NOT kept live -- `load_*` re-reads them from a
-    workspace inside each column's scope -- X_j(q) and I_j v_j are rematerialised per column, and a column's forward /
-    backward recursion runs depth-first so only one root-to-leaf path of dv, da, df is alive.  For every column
-    `emit_column(col, dc)` receives dc = {row: (d/dq value, d/dqd value)} for the structurally non-zero rows and emits
-    whatever depends on it (the outputs, or the -Minv product of the forward-dynamics gradient).
+    demand-ordered trace): v_j, X_j a_parent and the accumulated f_j are NOT kept live -- they are re-read from a
+    workspace -- X_j(q) and I_j v_j are rematerialised per column, and a column's forward / backward recursion runs
+    depth-first so only one root-to-leaf path of dv, da, df is alive.  The workspace reads are software-pipelined: the
+    whole visit sequence is known at generation time, so the loads of visit i + `prefetch` are issued at the start of
+    visit i (loader(kind, j) -> 6 fresh load nodes; kinds "v", "xa", "f").  For every column `emit_column(col, dc)`
+    receives dc = {row: (d/dq value, d/dqd value)} for the structurally non-zero rows and emits what depends on it.
     """
     n = spec.n
-    for col in (order if order is not None else range(n)):
+    cols = list(order if order is not None else range(n))
+    # static plan of load groups in execution order: (column, joint) visits in DFS pre-order of each column's subtree
+    plan = []
+    for col in cols:
+        for j in spec.subtree[col]:
+            plan.append((col, j))
+    issued = {}
+    state = {"next": 0, "pos": 0}
+
+    def issue_upto(limit):
+        while state["next"] < min(limit, len(plan)):
+            col, j = plan[state["next"]]
+            vals = {"v": loader("v", j)}
+            if j == col:
+                vals["xa"] = loader("xa", j)
+                if spec.parent[j] != -1:
+                    vals["f"] = loader("f", j)
+            issued[(col, j)] = vals
+            state["next"] += 1
+
+    for col in cols:
         mark = tr.cse_mark()
         Xc = {}
 
         def Xof(j):
+            if xof is not None:          # the caller owns the per-column X cache (recompute cores share it with v/a/f)
+                return xof(j)
             if j not in Xc:
                 Xc[j] = build_X_joint(tr, spec, j, q[j], trig[j])
             return Xc[j]
@@ -375,8 +398,11 @@ def rnea_grad_columns(tr, spec, I, q, qd, trig, load_v, load_xa, load_f, emit_co
 
         def visit(j, dv_p, da_p):
             s, p = spec.S_ind[j], spec.parent[j]
-            tr.fence()                       # pin this joint's workspace loads here (see grid_in_ws::sync)
-            vj = load_v(j)
+            tr.fence()                       # loads below are pinned after this point (see grid_in_ws::sync)
+            issue_upto(state["pos"] + 1 + prefetch)
+            state["pos"] += 1
+            got = issued.pop((col, j))
+            vj = got["v"]
             Iv = matvec(tr, I[j], vj)
             if j == col:
                 if p != -1:
@@ -387,7 +413,7 @@ def rnea_grad_columns(tr, spec, I, q, qd, trig, load_v, load_xa, load_f, emit_co
                     dvq = zeros6(tr)
                 dvqd = zeros6(tr)
                 dvqd[s] = tr.const(1.0)
-                daq = vadd(mxS(tr, s, dvq, qd[j]), mxS(tr, s, load_xa(j)))
+                daq = vadd(mxS(tr, s, dvq, qd[j]), mxS(tr, s, got["xa"]))
                 daqd = vadd(mxS(tr, s, dvqd, qd[j]), mxS(tr, s, vj))
             else:
                 X = Xof(j)
@@ -405,7 +431,7 @@ def rnea_grad_columns(tr, spec, I, q, qd, trig, load_v, load_xa, load_f, emit_co
                 Xch = Xof(c)
                 dfs = [mattvec_acc(tr, Xch, dfc[0], dfs[0]), mattvec_acc(tr, Xch, dfc[1], dfs[1])]
             if j == col and p != -1:
-                dfs[0] = vadd(dfs[0], fxS(tr, s, load_f(j)))
+                dfs[0] = vadd(dfs[0], fxS(tr, s, got["f"]))
             dc[j] = (dfs[0][s], dfs[1][s] + spec.damping[j] if (j == col and spec.damping[j] != 0.0) else dfs[1][s])
             return dfs
 
@@ -418,5 +444,4 @@ def rnea_grad_columns(tr, spec, I, q, qd, trig, load_v, load_xa, load_f, emit_co
             dc[k] = (cur[0][spec.S_ind[k]], cur[1][spec.S_ind[k]])
             c = k
         emit_column(col, dc)
-        tr.fence()
-        tr.cse_release(mark)
+        tr.cse_release(mark, keep=keep)

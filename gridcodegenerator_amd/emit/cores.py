@@ -323,7 +323,7 @@ def core_gradient_prep(spec, ws, kind, use_qdd=False):
     return tr
 
 
-def core_gradient_columns(spec, ws, with_minv):
+def core_gradient_columns(spec, ws, with_minv, prefetch=3):
     """Pass 2 (creation-order emission).  Column-serial gradient reading the workspace; with_minv also applies
     df_du[:, col] = -Minv_sym dc_du[:, col] per column.  Outputs: column `col` of d/dq (indices n*col..) then of d/dqd."""
     n = spec.n
@@ -333,7 +333,13 @@ def core_gradient_columns(spec, ws, with_minv):
     trig = [(tr.inp("in.ws(%d)" % (ws.SC + j)), tr.inp("in.ws(%d)" % (ws.SC + n + j))) if spec.uses_trig[j] else None
             for j in range(n)]
     I = alg.build_I(tr, spec)
-    load = lambda base: (lambda j: [tr.inp("in.ws(%d)" % (base + 6 * j + r)) for r in range(6)])
+    base = {"v": ws.V, "xa": ws.XA, "f": ws.F}
+    serial = [0]
+
+    def loader(kind, j):
+        # a fresh load node per request ("#k" keeps requests of the same slot distinct: each is its own global_load)
+        serial[0] += 1
+        return [tr.inp("in.ws(%d)/*%d*/" % (base[kind] + 6 * j + r, serial[0])) for r in range(6)]
 
     def emit_column(col, dc):
         rows = sorted(dc)
@@ -355,5 +361,133 @@ def core_gradient_columns(spec, ws, with_minv):
         for r in range(n):
             tr.out(n * n + n * col + r, hi[r])
 
-    alg.rnea_grad_columns(tr, spec, I, q, qd, trig, load(ws.V), load(ws.XA), load(ws.F), emit_column)
+    alg.rnea_grad_columns(tr, spec, I, q, qd, trig, loader, emit_column, prefetch=prefetch)
+    return tr
+
+
+# ------------------------------------------------------------------------------------------------
+# single-kernel column-serial cores with RECOMPUTATION (large robots)
+# ------------------------------------------------------------------------------------------------
+def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False):
+    """Column-serial gradient core that keeps almost nothing alive between columns: inside each column the velocities,
+    accelerations and accumulated forces it needs (path root -> column joint, and the column's subtree) are RECOMPUTED
+    from q, qd, qdd instead of being held in registers (the fused demand-ordered trace keeps 880-1160 values alive for
+    Atlas-30 and spills) or parked in an HBM workspace (two-pass variant).  ~1.6x the arithmetic, no spills.
+
+    kind "id": dc_du at (q, qd[, qdd]).  kind "fd": df_du; Minv and qdd are computed first (default) or read from the
+    inputs (use_qdd_minv: the reference's USE_QDD_MINV_FLAG variant; Minv entries are read where they are used)."""
+    n = spec.n
+    tr = Tracer()
+    q = [tr.inp("in.q(%d)" % j) for j in range(n)]
+    qd = [tr.inp("in.qd(%d)" % j) for j in range(n)]
+    g = tr.inp("gravity")
+    trig = alg.trig_from_q(tr, spec, q)
+    I = alg.build_I(tr, spec)
+    Minv = None
+    if kind == "fd" and not use_qdd_minv:
+        mark = tr.cse_mark()
+        u = [tr.inp("in.u(%d)" % j) for j in range(n)]
+        X = alg.build_X(tr, spec, q, trig)
+        Minv = alg.direct_minv(tr, spec, X, I)
+        c = alg.rnea(tr, spec, X, I, qd, None, g)[0]
+        qdd = alg.fd_finish(tr, spec, Minv, u, c)
+        qdd = list(qdd)
+        tr.fence()
+        tr.cse_release(mark, keep=[t.ref for pair in trig if pair is not None for t in pair])
+    elif kind == "fd" or use_qdd:
+        qdd = [tr.inp("in.qdd(%d)" % j) for j in range(n)]
+    else:
+        qdd = None
+    nz = alg.minv_zero_pattern(spec) if kind == "fd" else None
+
+    memo = {}
+    trig = list(trig)
+
+    def touch(j):
+        # first use of joint j in this column: launder its inputs IN PLACE, so the chains recomputed below are new values
+        # to the compiler (otherwise its CSE keeps the first column's v, a, f alive for all later columns and spills them)
+        if ("t", j) not in memo:
+            memo[("t", j)] = True
+            q[j] = tr.launder(q[j])
+            qd[j] = tr.launder(qd[j])
+            if trig[j] is not None:
+                trig[j] = tuple(tr.launder(t) for t in trig[j])
+            if qdd is not None:
+                qdd[j] = tr.launder(qdd[j])
+
+    def Xof(j):
+        if ("X", j) not in memo:
+            touch(j)
+            memo[("X", j)] = alg.build_X_joint(tr, spec, j, q[j], trig[j])
+        return memo[("X", j)]
+
+    def v_of(j):
+        if ("v", j) not in memo:
+            touch(j)
+            p, s = spec.parent[j], spec.S_ind[j]
+            if p == -1:
+                v = alg.zeros6(tr)
+                v[s] = qd[j]
+            else:
+                v = alg.matvec(tr, Xof(j), v_of(p))
+                v[s] = v[s] + qd[j]
+            memo[("v", j)] = v
+        return memo[("v", j)]
+
+    def xa_of(j):
+        if ("xa", j) not in memo:
+            p = spec.parent[j]
+            memo[("xa", j)] = alg.matvec(tr, Xof(j), a_of(p)) if p != -1 else [Xof(j)[r][5] * g for r in range(6)]
+        return memo[("xa", j)]
+
+    def a_of(j):
+        if ("a", j) not in memo:
+            p, s = spec.parent[j], spec.S_ind[j]
+            touch(j)
+            a = list(xa_of(j))
+            if p != -1:
+                a = alg.vadd(a, alg.mxS(tr, s, v_of(j), qd[j]))
+            if qdd is not None:
+                a[s] = a[s] + qdd[j]
+            memo[("a", j)] = a
+        return memo[("a", j)]
+
+    def facc(j):
+        if ("f", j) not in memo:
+            v = v_of(j)
+            f = alg.vadd(alg.matvec(tr, I[j], a_of(j)), alg.fxv(tr, v, alg.matvec(tr, I[j], v)))
+            for ch in spec.children[j]:
+                f = alg.mattvec_acc(tr, Xof(ch), facc(ch), f)
+            memo[("f", j)] = f
+        return memo[("f", j)]
+
+    def loader(kind_, j):
+        return {"v": v_of, "xa": xa_of, "f": facc}[kind_](j)
+
+    def minv_entry(r, k):
+        a, b = (r, k) if r <= k else (k, r)
+        if not nz[a][b]:
+            return None
+        return Minv[a][b] if Minv is not None else tr.inp("in.Minv(%d)" % (n * b + a))
+
+    def emit_column(col, dc):
+        memo.clear()
+        rows = sorted(dc)
+        if kind != "fd":
+            for half in (0, 1):
+                for r in range(n):
+                    e = dc.get(r)
+                    tr.out(half * n * n + n * col + r, e[half] if e is not None else tr.zero())
+            return
+        hi = []
+        for r in range(n):
+            m = [(k, minv_entry(r, k)) for k in rows]
+            m = [(k, e) for (k, e) in m if e is not None]
+            tr.out(n * col + r, -tr.dot([(e, dc[k][0]) for (k, e) in m]))
+            hi.append(-tr.dot([(e, dc[k][1]) for (k, e) in m]))
+        for r in range(n):
+            tr.out(n * n + n * col + r, hi[r])
+
+    keep = ([t.ref for row in Minv for t in row if t is not None] if Minv is not None else [])
+    alg.rnea_grad_columns(tr, spec, I, q, qd, trig, loader, emit_column, prefetch=0, xof=Xof, keep=keep)
     return tr

@@ -315,6 +315,16 @@ class Tracer:
         self.outputs.append((dst_expr, val.ref))
         self.out_pos.append(len(self.nodes))       # creation-order emission places the store here
 
+    def launder(self, a):
+        """Same value, but opaque to the compiler from here on (an empty asm with the register as in/out operand): a later
+        expression over the laundered value is NOT a common subexpression of the same expression over the original, so
+        hipcc cannot undo a deliberate recomputation by keeping the first result alive (and spilling it)."""
+        if isinstance(a.ref, float):
+            return a
+        sign = 1 if a.ref > 0 else -1
+        self._launder_serial = getattr(self, "_launder_serial", 0) + 1
+        return V(self, sign * self._node(("lnd", abs(a.ref), self._launder_serial, None)))
+
     def fence(self):
         """Scheduling fence at this point of the trace (creation-order emission only)."""
         self.fences.append(len(self.nodes))
@@ -336,7 +346,7 @@ class Tracer:
         op, a, b, c = self.nodes[k]
         if op == "in":
             return ()
-        if op in ("lo", "hi"):
+        if op in ("lo", "hi", "lnd"):
             return (a,)
         if op.startswith("pk"):
             return tuple(abs(r) for pair in (a, b, c) if pair is not None for r in pair if not isinstance(r, float))
@@ -440,6 +450,9 @@ class Tracer:
                 lines.append("%sconst C t%d = grid_fma(%s, %s, %s);" % (indent, k, self._opnd(a), self._opnd(b), self._opnd(c)))
             elif op == "rcp":
                 lines.append("%sconst C t%d = (C)1 / %s;" % (indent, k, self._opnd(a)))
+            elif op == "lnd":
+                count[0] -= 1       # no instruction when the source dies here (the usual case)
+                lines.append("%sC t%d = %s; GRID_LAUNDER(t%d);" % (indent, k, self._opnd(a), k))
             elif op in ("lo", "hi"):
                 count[0] -= 1       # a register half of a packed value: no instruction
             elif op == "pkfma":
@@ -545,6 +558,8 @@ class Tracer:
                 val[k] = (rnd(get(a[0]) * get(b[0])), rnd(get(a[1]) * get(b[1])))
             elif op == "pkadd":
                 val[k] = (rnd(get(a[0]) + get(b[0])), rnd(get(a[1]) + get(b[1])))
+            elif op == "lnd":
+                val[k] = val[a]
             elif op == "lo":
                 val[k] = val[a][0]
             elif op == "hi":

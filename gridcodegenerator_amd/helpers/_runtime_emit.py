@@ -33,8 +33,10 @@ class RuntimeEmitMixin:
             "// scheduling fence used inside the straight-line bodies (device code only)",
             "#if defined(__HIP_DEVICE_COMPILE__)",
             "#define GRID_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)",
+            "#define GRID_LAUNDER(x) asm volatile(\"\" : \"+v\"(x))   // same value, new identity: defeats CSE of deliberate recomputation",
             "#else",
             "#define GRID_SCHED_FENCE()",
+            "#define GRID_LAUNDER(x) ((void)0)",
             "#endif",
             "// single kernel timing helper code",
             "#define time_delta_us_timespec(start,end) (1e6*static_cast<double>(end.tv_sec - start.tv_sec)+1e-3*static_cast<double>(end.tv_nsec - start.tv_nsec))",
@@ -314,31 +316,44 @@ class RuntimeEmitMixin:
             "template <typename T, int ROW, int NL, int CH, int BASE0, int LEN0, int BASE1>",
             "struct grid_out_staged {",
             "    T *s_wave; T *d_dst; int k0; int lane; int W; int NUM_TIMESTEPS;",
-            "    __device__ __forceinline__ void flush(const int chunk){",
-            "        const int lbase = chunk*CH; const int len = (NL - lbase < CH) ? (NL - lbase) : CH;",
-            "        const int base = (lbase < LEN0) ? (BASE0 + lbase) : (BASE1 + lbase - LEN0);",
+            "    // flush: LDS holds the chunk config-major, [cfg][len].  Lanes are split into G = 64/P groups of P = pow2ceil(len)",
+            "    // lanes; group g of iteration t writes configuration G*t + g, lane ii of the group element ii.  Every address is",
+            "    // (wave-uniform base advanced by a constant per iteration) + (a per-lane offset computed once): no per-element",
+            "    // integer arithmetic (the earlier flat f -> (cfg, i) split by division cost ~9 VALU instructions per value:",
+            "    // a third of all executed instructions of the Atlas kernels).",
+            "    template <int LEN>",
+            "    __device__ __forceinline__ void flush_len(const int base){",
+            "        constexpr int P = (LEN <= 1) ? 1 : (LEN <= 2) ? 2 : (LEN <= 4) ? 4 : (LEN <= 8) ? 8 : (LEN <= 16) ? 16 : (LEN <= 32) ? 32 : 64;",
+            "        constexpr int G = GRID_WAVE_SIZE / P;",
             "        const int nvalid = min(W, NUM_TIMESTEPS - k0);",
-            "        const int ln = grid_opaque(lane);",
+            "        const int g = lane / P; const int ii = lane % P;",
             "        grid_wave_sync();",
-            "        T *dst = d_dst + (size_t)k0*ROW + base;           // wave-uniform base; per-lane offsets stay 32-bit",
-            "        T tmp[CH];",
-            "        #pragma unroll",
-            "        for (int t = 0; t < len; t++){tmp[t] = s_wave[t*W + ln];}      // LDS holds the chunk flat: f = cfg*len + i",
-            "        if (nvalid == W){     // full tile (wave-uniform): unpredicated stores (98 exec-mask branches cost ~10 us)",
-            "            #pragma unroll",
-            "            for (int t = 0; t < len; t++){",
-            "                const int f = t*W + ln; const int cfg = f / len; const int i = f - cfg*len;",
-            "                dst[(unsigned)(cfg*ROW + i)] = tmp[t];",
+            "        if (W != GRID_WAVE_SIZE){           // partial wavefront (block size not a multiple of 64): generic path",
+            "            for (int f = lane; f < nvalid*LEN; f += W){",
+            "                const int cfg = f / LEN; const int i = f - cfg*LEN;",
+            "                d_dst[(size_t)(k0 + cfg)*ROW + base + i] = s_wave[f];",
             "            }",
             "        }",
-            "        else {",
-            "            #pragma unroll",
-            "            for (int t = 0; t < len; t++){",
-            "                const int f = t*W + ln; const int cfg = f / len; const int i = f - cfg*len;",
-            "                if (cfg < nvalid){dst[(unsigned)(cfg*ROW + i)] = tmp[t];}",
+            "        else if (ii < LEN){",
+            "            const T *src = s_wave + (g*LEN + ii);",
+            "            T *dst = d_dst + (size_t)k0*ROW + base + (unsigned)(g*ROW + ii);",
+            "            // partially unrolled on purpose: 8 LDS reads in flight, small code (full unrolling made the Atlas kernels",
+            "            // take 7-25 minutes to compile)",
+            "            if (nvalid == GRID_WAVE_SIZE){   // full tile: no per-iteration predicate",
+            "                #pragma unroll 8",
+            "                for (int t = 0; t < GRID_WAVE_SIZE/G; t++){dst[(unsigned)(t*G*ROW)] = src[t*G*LEN];}",
+            "            }",
+            "            else {",
+            "                #pragma unroll 2",
+            "                for (int t = 0; t < GRID_WAVE_SIZE/G; t++){if (t*G + g < nvalid){dst[(unsigned)(t*G*ROW)] = src[t*G*LEN];}}",
             "            }",
             "        }",
             "        grid_wave_sync();",
+            "    }",
+            "    __device__ __forceinline__ void flush(const int chunk){",
+            "        const int lbase = chunk*CH;",
+            "        const int base = (lbase < LEN0) ? (BASE0 + lbase) : (BASE1 + lbase - LEN0);",
+            "        if (NL - lbase < CH){flush_len<(NL % CH == 0) ? CH : (NL % CH)>(base);} else {flush_len<CH>(base);}",
             "    }",
             "    __device__ __forceinline__ void put(const int i, const T v){",
             "        const int lbase = (i / CH)*CH; const int len = (NL - lbase < CH) ? (NL - lbase) : CH;",

@@ -105,7 +105,8 @@ def _build_library_locked(robot_name, precision, force, verbose, extra_flags, ge
         gen_kwargs = dict(DEFAULT_GEN_KWARGS.get(robot_name, {}))
     p = library_paths(robot_name, precision)
     flags = ["--offload-arch=" + ARCH, "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-I" + INCLUDE_DIR] + list(extra_flags)
-    fp = _source_fingerprint(repr(sorted(gen_kwargs.items())) + precision + " ".join(flags))
+    # (no absolute paths in the fingerprint: the same tree is mounted at different locations on different boxes)
+    fp = _source_fingerprint(repr(sorted(gen_kwargs.items())) + precision + " ".join(f for f in flags if not f.startswith("-I")))
     if not force and os.path.exists(p["lib"]) and os.path.exists(p["stamp"]):
         with open(p["stamp"]) as fh:
             if fh.read().strip() == fp:

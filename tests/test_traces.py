@@ -125,3 +125,59 @@ def test_fp32_roundoff_budget(name, bound, setup):
     ref = _grad_flat(O.fd_grad(T, q, qd, u), spec.n)
     got = _run(cores.core_forward_dynamics_gradient(spec, False), _inputs(spec.n, q, qd, u=u), "float32")
     assert relerr(got, ref)[0] < bound
+
+
+# ---- explicit schedules for large robots: two-pass (workspace) cores and the recomputing single-kernel cores ----------
+def _scatter(tr, outs, width):
+    got = np.zeros((outs.shape[0], width))
+    for (dst, _), col in zip(tr.outputs, outs.T):
+        got[:, int(dst)] = col
+    return got
+
+
+@pytest.mark.parametrize("kind", ["id", "id_qdd", "fd"])
+def test_two_pass_cores(robot_name, setup, kind):
+    """prep core -> workspace values -> column-serial core == oracle (what *_prep_kernel + *_columns_kernel compute)."""
+    import re
+    spec, T, q, qd, u = setup(robot_name)
+    n = spec.n
+    fd = (kind == "fd")
+    ws = cores.WorkspaceMap(spec, with_minv=fd)
+    prep = cores.core_gradient_prep(spec, ws, "fd" if fd else "id", use_qdd=(kind == "id_qdd"))
+    wsv = _scatter(prep, _run(prep, _inputs(n, q, qd, u=u, qdd=u)), ws.count)
+    cols = cores.core_gradient_columns(spec, ws, fd)
+    inputs = _inputs(n, q, qd)
+    for k in range(1, len(cols.nodes)):
+        op, a = cols.nodes[k][0], cols.nodes[k][1]
+        if op == "in" and a.startswith("in.ws("):
+            inputs[a] = wsv[:, int(re.match(r"in\.ws\((\d+)\)", a).group(1))]
+    got = _scatter(cols, _run(cols, inputs), 2 * n * n)
+    if fd:
+        ref = _grad_flat(O.fd_grad(T, q, qd, u), n)
+    else:
+        ref = _grad_flat(O.rnea_grad(T, q, qd, u if kind == "id_qdd" else None), n)
+    assert relerr(got, ref)[0] < 1e-12
+
+
+@pytest.mark.parametrize("variant", ["id", "id_qdd", "fd", "fd_qdd_minv"])
+def test_recompute_cores(robot_name, setup, variant):
+    """Column-serial cores that recompute v, a, f per column (single-kernel schedule for n > 12) == oracle."""
+    spec, T, q, qd, u = setup(robot_name)
+    n = spec.n
+    ref_fd, parts = O.fd_grad(T, q, qd, u, return_parts=True)
+    if variant.startswith("id"):
+        use_qdd = variant.endswith("qdd")
+        tr = cores.core_gradient_recompute(spec, "id", use_qdd=use_qdd)
+        inputs = _inputs(n, q, qd, qdd=u if use_qdd else None)
+        ref = _grad_flat(O.rnea_grad(T, q, qd, u if use_qdd else None), n)
+    elif variant == "fd":
+        tr = cores.core_gradient_recompute(spec, "fd")
+        inputs = _inputs(n, q, qd, u=u)
+        ref = _grad_flat(ref_fd, n)
+    else:
+        tr = cores.core_gradient_recompute(spec, "fd", use_qdd_minv=True)
+        inputs = _inputs(n, q, qd, qdd=parts["qdd"], Minv_flat=O.flat_colmajor(np.triu(parts["Minv"])))
+        ref = _grad_flat(ref_fd, n)
+    got = _scatter(tr, _run(tr, inputs), 2 * n * n)
+    assert relerr(got, ref)[0] < 1e-12
+    assert tr.op_counts().get("lnd", 0) > 0      # inputs are laundered per column (keeps hipcc from undoing the recomputation)
