@@ -89,7 +89,8 @@ int grid_get_split(grid_handle *h, int alg, int num_timesteps);
  * For robots whose gradient working set exceeds the register file (Atlas-30) the generator also emits a two-kernel
  * variant: pass 1 (RNEA [+ Minv, qdd]) writes per-joint quantities to a tile-major SoA workspace in HBM, pass 2 runs the
  * gradient column by column re-reading them.  grid_workspace_count: elements per configuration (0 = not generated).
- * grid_set_pipeline: 0 = automatic (default: use it where generated), 1 = fused kernel only, 2 = two-pass.
+ * grid_set_pipeline: 0 = automatic (single kernel: measured faster since the recomputing column schedule), 1 = single kernel,
+ * 2 = two-pass (error when the generator emitted none for this robot).
  * The workspace lives in the handle and grows on demand (first call at a new batch size allocates). */
 int grid_workspace_count(int alg);
 int grid_set_pipeline(grid_handle *h, int alg, int mode);
