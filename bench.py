@@ -42,16 +42,19 @@ def make_inputs(n, K, seed):
     return q, qd, u
 
 
-def cpu_baseline(robot_name, q, qd, u, passes):
-    """numpy float64 oracle on the host cores (single process => cores = 1)."""
+def cpu_baseline(robot_name, q, qd, u, seconds):
+    """numpy float64 oracle on the host cores (single process => cores = 1): whole passes over the same batch until about
+    `seconds` of CPU work have been done (at least one pass)."""
     from gridcodegenerator_amd.robots import get_robot
     from oracle import rbd_oracle as O
     T = O.RobotTables(get_robot(robot_name))
     q64, qd64, u64 = (a.astype(np.float64) for a in (q, qd, u))
     O.fd_grad(T, q64[:64], qd64[:64], u64[:64])  # warm numpy
+    passes = 0
     t0 = time.perf_counter()
-    for _ in range(passes):
+    while passes == 0 or time.perf_counter() - t0 < seconds:
         O.fd_grad(T, q64, qd64, u64)
+        passes += 1
     dt = time.perf_counter() - t0
     return dict(value=passes * q.shape[0] / dt, unit="evals/s", cores=1, kind="port",
                 sample="%d pass(es) of oracle.fd_grad (numpy float64, batch-vectorised) over the same %d-configuration batch, %.1f s"
@@ -67,7 +70,8 @@ def main():
     ap.add_argument("--batch", type=int, default=16384, help="configurations per GPU")
     ap.add_argument("--precision", default="fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-passes", type=int, default=2)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work of the cpu_baseline sample (whole passes)")
+    ap.add_argument("--prewarm-s", type=float, default=0.3, help="seconds of untimed launches before the warm-up (clock ramp)")
     ap.add_argument("--blocks", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--split", type=int, default=0, help="column-split factor of the gradient kernel: 0 auto, 1 never, S force")
@@ -101,11 +105,19 @@ def main():
         h.forward_dynamics_gradient_device(d_out.data_ptr(), d_in.data_ptr(), 3 * n, K, gravity=GRAVITY,
                                            blocks=args.blocks, threads=args.threads, stream=stream)
 
+    # Bring the GPU out of its idle power state first (an MI355X box idles in a low-power state and the default run is only
+    # ~3 ms of kernels): launch the same step for --prewarm-s seconds of wall clock.  Not counted as warm-up or steps.
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < args.prewarm_s:
+        for _ in range(50):
+            step()
+        torch.cuda.synchronize()
+
     elapsed = sharding.timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, dist, reduce_device="cuda")
 
     # in-stream kernel duration (HIP events recorded on the launch stream by the C ABI)
     kern_ms = h.time_device(host.ALG_FD_DU, d_out.data_ptr(), d_in.data_ptr(), 3 * n, K, gravity=GRAVITY,
-                            blocks=args.blocks, threads=args.threads, stream=stream, reps=max(20, min(args.steps, 200)))
+                            blocks=args.blocks, threads=args.threads, stream=stream, reps=max(20, min(args.steps, 200)))   # average over reps
     finite = bool(torch.isfinite(d_out).all().item())
 
     if rank == 0:
@@ -142,12 +154,13 @@ def main():
             kern = {}
             bufs = {a: torch.empty((K, host.output_size(a, n)), dtype=torch.float32, device="cuda") for a in range(5)}
             for a in range(5):
-                ms = h.time_device(a, bufs[a].data_ptr(), d_in.data_ptr(), 3 * n, K, gravity=GRAVITY, stream=stream, reps=50)
+                h.time_device(a, bufs[a].data_ptr(), d_in.data_ptr(), 3 * n, K, gravity=GRAVITY, stream=stream, reps=200)   # ramp
+                ms = h.time_device(a, bufs[a].data_ptr(), d_in.data_ptr(), 3 * n, K, gravity=GRAVITY, stream=stream, reps=200)
                 by = host.algorithmic_bytes(a, n) * K
                 kern[host.ALG_NAMES[a]] = {"avg_us": 1e3 * ms, "evals_per_s": K / (ms * 1e-3), "alg_GBps": by / (ms * 1e-3) / 1e9}
             out["kernels"] = kern
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.robot, q, qd, u, args.cpu_passes)
+            out["cpu_baseline"] = cpu_baseline(args.robot, q, qd, u, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     h.close()
     if dist is not None:

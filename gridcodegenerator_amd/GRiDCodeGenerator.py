@@ -24,6 +24,9 @@ Generation-time knobs that have no reference counterpart are keyword-only:
     pipeline         "auto" | bool    also emit the two-pass (workspace) variants of the gradient kernels; auto: n > 12
     grad_schedule    "auto" | "fused" | "recompute"   body of the single-kernel gradient cores: demand-ordered fused trace, or
                      column-serial with per-column recomputation of v, a, f (no spills for large robots); auto: recompute for n > 12
+    grad_table       bool             recompute schedule only: park sin q, cos q, qd, qdd in a per-wave LDS table and re-load them per
+                     column instead of keeping them in registers (Atlas-30: no scratch at all, but 16 % more instructions and
+                     measured slower: 186 vs 163 us at K = 32768) -- off by default, exercised by the mixed5 test robot
     waves_per_simd                    __launch_bounds__ occupancy hint for the unsplit kernels (caps registers at 512/w)
     grad_splits      "auto" | list    column-split variants of the two gradient kernels to emit (small-batch speed)
     fence_every                       extra scheduling fence every N emitted statements (0 = none).  A fence always
@@ -39,7 +42,7 @@ from .helpers._text import TextMixin
 class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin):
     def __init__(self, robotObj, DEBUG_MODE=False, NEED_PRINT_MAT=False, USE_DYNAMIC_SHARED_MEM=True,
                  FILE_NAMESPACE="grid", *, precision="fp32", trig="fast", suggested_threads=64, max_threads=256,
-                 out_chunk=64, emit_order="demand", emit_inner_api=True, suggested_max_blocks=2048, fence_every=0, grad_splits="auto", out_mode="staged", packed=False, waves_per_simd=1, pipeline="auto", grad_schedule="auto"):
+                 out_chunk=64, emit_order="demand", emit_inner_api=True, suggested_max_blocks=2048, fence_every=0, grad_splits="auto", out_mode="staged", packed=False, waves_per_simd=1, pipeline="auto", grad_schedule="auto", grad_table=False):
         if precision not in ("fp32", "fp64"):
             raise ValueError("precision must be 'fp32' or 'fp64'")
         if trig not in ("fast", "libm", "f64"):
@@ -72,6 +75,7 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin):
         self.use_pipeline = (self.spec.n > 12) if pipeline == "auto" else bool(pipeline)
         assert grad_schedule in ("auto", "fused", "recompute")
         self.grad_schedule = ("recompute" if self.spec.n > 12 else "fused") if grad_schedule == "auto" else grad_schedule
+        self.grad_table = bool(grad_table) and self.grad_schedule == "recompute"
         self.kernel_instances = []
         self.split_stats = {}
         self.emit_inner_api = bool(emit_inner_api)

@@ -10,6 +10,7 @@ coalesced staging (helpers/_runtime_emit.py) and a grid-stride loop over 64-conf
 """
 from ..emit import cores
 
+WAVE = 64
 MAX_IN_PIECE = 64   # inputs wider than this are staged through LDS in pieces (keeps LDS/wave small)
 
 
@@ -31,8 +32,8 @@ class AlgorithmEmitMixin:
         def chunk(n_out):
             return n_out if n_out <= cap else _largest_divisor_leq(n_out, cap)
 
-        def pieces(total):
-            return [min(MAX_IN_PIECE, total - o) for o in range(0, total, MAX_IN_PIECE)]
+        def pieces(total, cap_in=MAX_IN_PIECE):
+            return [min(cap_in, total - o) for o in range(0, total, cap_in)]
 
         lay = {
             "ID": dict(inputs=[("q_qd", 2 * n), ("qdd", n)], n_out=n),
@@ -41,10 +42,25 @@ class AlgorithmEmitMixin:
             "ID_DU": dict(inputs=[("q_qd", 2 * n), ("qdd", n)], n_out=2 * n * n),
             "FD_DU": dict(inputs=[("q_qd_u", 3 * n), ("qdd", n), ("Minv", n * n)], n_out=2 * n * n),
         }
-        for d in lay.values():
+        for (alg, d) in lay.items():
             d["chunk"] = chunk(d["n_out"])
-            d["inputs"] = [(nm, p) for (nm, tot) in d["inputs"] for p in pieces(tot)]
+            d["in_piece"] = MAX_IN_PIECE
+            if self.grad_schedule == "recompute" and alg in ("ID_DU", "FD_DU"):
+                d["chunk"] = n          # one gradient column per flush
+            if self.grad_table and alg in ("ID_DU", "FD_DU"):
+                # recomputing column-serial kernels: one gradient column per flush, inputs staged in pieces of <= 32 and a
+                # lane-private LDS table behind the staging region (Atlas-30: 64*(32 + 120)*4 B = 38.9 KB per wave, four
+                # single-wave blocks per CU)
+                d["chunk"] = n
+                d["in_piece"] = 32
+                d["table"] = cores.recompute_table_size(self.spec, "fd" if alg == "FD_DU" else "id", use_qdd=True)
+            d["inputs"] = [(nm, p) for (nm, tot) in d["inputs"] for p in pieces(tot, d["in_piece"])]
         self.io_layout = lay
+        # dynamic LDS of one block stays <= 64 KB (no hipFuncSetAttribute needed): cap the block size accordingly
+        worst = max(self.lds_per_wave(alg) for alg in lay) * 4
+        while self.max_threads > WAVE and (self.max_threads // WAVE) * worst > 65536:
+            self.max_threads -= WAVE
+        self.suggested_threads = min(self.suggested_threads, self.max_threads)
 
     # ------------------------------------------------------------------------------------------
     # generic pieces
@@ -73,12 +89,13 @@ class AlgorithmEmitMixin:
             "template <typename T, typename C, typename In, typename Out>",
             "__host__ __device__ __forceinline__",
             "void %s(const In &in, Out &out, const T gravity)" % name, tracer,
-            store=lambda dst, val: "out.put(%s, (T)(%s));%s" % (dst, val, fence), order=order, fence_stmt=fence_stmt)
+            store=lambda dst, val: ("in.tab_put(%s, (T)(%s));" % (dst[4:], val)) if isinstance(dst, str) and dst.startswith("tab:")
+            else "out.put(%s, (T)(%s));%s" % (dst, val, fence), order=order, fence_stmt=fence_stmt)
 
-    def _emit_load(self, dst, src, total, stride):
+    def _emit_load(self, dst, src, total, stride, piece=MAX_IN_PIECE):
         off = 0
         while off < total:
-            p = min(MAX_IN_PIECE, total - off)
+            p = min(piece, total - off)
             self.gen_add_code_line("grid_load_tile<T,%d>(%s + %d, %s + %d, %s, k0, it, NUM_TIMESTEPS, s_wave);"
                                    % (p, dst, off, src, off, stride))
             off += p
@@ -118,8 +135,9 @@ class AlgorithmEmitMixin:
                       "gridDim must be a multiple of %d (use the *_split_launch helper)" % len(parts)]
         self.gen_add_func_doc(doc, notes, params, None)
         self.gen_add_code_line("template <typename T, typename C = typename grid_compute<T>::type>")
-        # split kernels exist to put >= 2 waves on a SIMD: cap them at 256 registers (2nd argument = waves per SIMD)
-        occ = 2 if parts else self.waves_per_simd
+        # the 2-way split is the one used when the batch fills the chip: cap it at 256 registers so two waves share a SIMD
+        # (2nd argument = waves per SIMD).  Finer splits only run when there are fewer waves than SIMDs: no cap, no spills.
+        occ = 2 if (parts and len(parts) == 2) else self.waves_per_simd
         self.gen_add_code_line("__global__ __launch_bounds__(GRID_MAX_THREADS%s)" % (", %d" % occ if occ > 1 else ""))
         self.gen_add_code_line(sig + " {", True)
         self.gen_add_code_lines([
@@ -129,8 +147,10 @@ class AlgorithmEmitMixin:
             "for (int k0 = it.k0_first; k0 < NUM_TIMESTEPS; k0 += it.k0_step){",
         ])
         self.indent_level += 1
+        piece = self.io_layout[alg]["in_piece"]
+        table = self.io_layout[alg].get("table", 0) if not parts else 0
         self.gen_add_code_line("T s_%s[%d];" % (pname, pcount))
-        self._emit_load("s_" + pname, "d_" + pname, pcount, pstride)
+        self._emit_load("s_" + pname, "d_" + pname, pcount, pstride, piece)
         for (ename, ecount) in extras:
             if ecount > MAX_IN_PIECE:
                 # large optional inputs (Minv of a 30-joint robot: 900 values) are read where they are used, straight from
@@ -138,8 +158,12 @@ class AlgorithmEmitMixin:
                 self.gen_add_code_line("const T *s_%s = d_%s + (size_t)min(k0 + it.lane, NUM_TIMESTEPS - 1)*%d;" % (ename, ename, ecount))
             else:
                 self.gen_add_code_line("T s_%s[%d];" % (ename, ecount))
-                self._emit_load("s_" + ename, "d_" + ename, ecount, str(ecount))
-        self.gen_add_code_line("const grid_in_ptrs<T> in = {%s};" % accessor)
+                self._emit_load("s_" + ename, "d_" + ename, ecount, str(ecount), piece)
+        if table:
+            self.gen_add_code_line("const grid_in_lds<T> in = {%s, s_wave + %d, it.lane};   // table behind the staging region"
+                                   % (accessor, self.lds_per_wave(alg) - WAVE * table))
+        else:
+            self.gen_add_code_line("const grid_in_ptrs<T> in = {%s};" % accessor)
         grav = "gravity" if has_gravity else "static_cast<T>(0)"
         direct = (self.out_mode == "direct")
         if direct:
@@ -281,13 +305,15 @@ class AlgorithmEmitMixin:
         self.gen_add_code_line("")
 
     def _choose_splits(self, builder):
-        """Column-split variants worth emitting: [(S, parts, worst part's op count)], each step improving >= 10 %."""
+        """Column-split variants worth emitting: [(S, parts, worst part's op count)], each step improving >= 3 %."""
         n = self.spec.n
         if self.grad_splits == "auto":
             # large robots: the split kernels need > 256 registers per column group, spill, take 10-25 minutes each to
             # compile and were slower than the unsplit kernel (profiles/r01/sweep_atlas30_split.txt): none by default
-            cand = list(range(2, n + 1)) if n <= 8 else ([2, 4] if n <= 12 else [])
-            limit = 3
+            # small robots: 2 (full chip, two waves per SIMD), 3 and 4 (K = 16384 is 256 tiles: 4 x 256 = one wave on every
+            # SIMD of an MI355X, measured best: 11.5 us vs 12.4 (S=3) vs 17.7 (S=1)) and one column per block for tiny batches
+            cand = sorted(set([2, 3, 4, n])) if n <= 8 else ([2, 4] if n <= 12 else [])
+            limit = 4
         else:
             cand = [int(S) for S in self.grad_splits]
             limit = len(cand)
@@ -301,7 +327,7 @@ class AlgorithmEmitMixin:
             parts, est = cores.balanced_column_split(self.spec, S, cost)
             if len(parts) != S or any(not c for c in parts):
                 continue
-            if self.grad_splits != "auto" or est < 0.9 * last:
+            if self.grad_splits != "auto" or n <= 8 or est < 0.97 * last:
                 picked.append((S, parts, est))
                 last = est
         if self.grad_splits == "auto" and len(picked) > limit > 1:      # keep the coarsest, the finest and spread the rest
@@ -475,8 +501,7 @@ class AlgorithmEmitMixin:
         self._emit_kernel("ID", "inverse_dynamics_kernel", "inverse_dynamics_core" + ("_qdd" if use_qdd_input else ""),
                           "Compute the RNEA (Recursive Newton-Euler Algorithm)", "c", ("q_qd", 2 * n, "stride_q_qd"),
                           [("qdd", n)] if use_qdd_input else [], True,
-                          "s_q_qd, s_q_qd + %d, nullptr, %s, nullptr" % (n, "s_qdd" if use_qdd_input else "nullptr"),
-                          chunk=n if self.grad_schedule == "recompute" else None)
+                          "s_q_qd, s_q_qd + %d, nullptr, %s, nullptr" % (n, "s_qdd" if use_qdd_input else "nullptr"))
 
     def gen_inverse_dynamics_host(self, mode=0):
         def pre(mode):
@@ -656,8 +681,11 @@ class AlgorithmEmitMixin:
                                  "__host__ __device__ __forceinline__",
                                  "void inverse_dynamics_gradient_device(T *s_dc_du, const T *s_q, const T *s_qd, %sconst robotModel<T> *d_robotModel, const T gravity) {"
                                  % ("const T *s_qdd, " if use_qdd_input else "")], True)
+        tab = self.io_layout["ID_DU"].get("table", 0)
+        if tab:
+            self.gen_add_code_line("T s_tab[%d];   // lane-private table of the recomputing core" % tab)
         self.gen_add_code_lines(["(void)d_robotModel;",
-                                 "const grid_in_ptrs<T> in = {s_q, s_qd, nullptr, %s, nullptr};" % ("s_qdd" if use_qdd_input else "nullptr"),
+                                 "const grid_in_ptrs<T> in = {s_q, s_qd, nullptr, %s, nullptr%s};" % ("s_qdd" if use_qdd_input else "nullptr", ", s_tab" if tab else ""),
                                  "grid_out_ptr<T> out = {s_dc_du};",
                                  "inverse_dynamics_gradient_core%s<T,C>(in, out, gravity);" % ("_qdd" if use_qdd_input else "")])
         self.gen_add_end_function()
@@ -693,7 +721,7 @@ class AlgorithmEmitMixin:
             doc = "RNEA + analytical gradient core: dc_du = [dc/dq | dc/dqd] at (q, qd%s)" % (", qdd" if use_qdd else ", 0")
             if self.grad_schedule == "recompute":
                 self._emit_core("inverse_dynamics_gradient_core" + ("_qdd" if use_qdd else ""), doc + " -- column-serial, recomputing",
-                                cores.core_gradient_recompute(self.spec, "id", use_qdd=use_qdd), order="creation")
+                                cores.core_gradient_recompute(self.spec, "id", use_qdd=use_qdd, table=self.grad_table), order="creation")
             else:
                 self._emit_core("inverse_dynamics_gradient_core" + ("_qdd" if use_qdd else ""), doc,
                                 cores.core_inverse_dynamics_gradient(self.spec, use_qdd))
@@ -732,6 +760,10 @@ class AlgorithmEmitMixin:
                                  "__host__ __device__ __forceinline__",
                                  "void forward_dynamics_gradient_device(T *s_df_du, const T *s_q, const T *s_qd, %sconst robotModel<T> *d_robotModel, const T gravity) {" % extra], True)
         acc = "s_q, s_qd, nullptr, s_qdd, s_Minv" if use_qdd_Minv_input else "s_q, s_qd, s_u, nullptr, nullptr"
+        tab = self.io_layout["FD_DU"].get("table", 0)
+        if tab:
+            self.gen_add_code_line("T s_tab[%d];   // lane-private table of the recomputing core" % tab)
+            acc += ", s_tab"
         self.gen_add_code_lines(["(void)d_robotModel;",
                                  "const grid_in_ptrs<T> in = {%s};" % acc,
                                  "grid_out_ptr<T> out = {s_df_du};",
@@ -774,10 +806,10 @@ class AlgorithmEmitMixin:
         if self.grad_schedule == "recompute":
             self._emit_core("forward_dynamics_gradient_core",
                             "Forward-dynamics gradient core: Minv, RNEA(0), qdd, then column-serial dRNEA (recomputing v, a, f per column) and -Minv*dc_du",
-                            cores.core_gradient_recompute(self.spec, "fd"), order="creation")
+                            cores.core_gradient_recompute(self.spec, "fd", table=self.grad_table), order="creation")
             self._emit_core("forward_dynamics_gradient_core_qdd_minv",
                             "Forward-dynamics gradient core with qdd and (upper triangular) Minv supplied -- column-serial, recomputing",
-                            cores.core_gradient_recompute(self.spec, "fd", use_qdd_minv=True), order="creation")
+                            cores.core_gradient_recompute(self.spec, "fd", use_qdd_minv=True, table=self.grad_table), order="creation")
         else:
             self._emit_core("forward_dynamics_gradient_core",
                             "Forward-dynamics gradient core (fused): Minv, RNEA(0), qdd, RNEA(qdd), dRNEA, -Minv*dc_du; out = [dqdd/dq | dqdd/dqd]",

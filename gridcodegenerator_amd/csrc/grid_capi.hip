@@ -198,11 +198,11 @@ int grid_forward_dynamics_gradient(grid_handle *h, const float *h_q_qd_u, const 
 
 // ---- device-pointer launches ------------------------------------------------------------------
 // Column-split choice (gradient kernels, default input variants only).  Splitting trades repeated prefix work (X(q), Minv,
-// RNEA) for more wavefronts.  Measured on MI355X (iiwa-7 FD gradient, tools/exp_variants.py): it pays while the batch leaves
-// CUs idle -- up to ~3 single-wave workgroups per CU (different column groups on one CU contend for instruction fetch) --
-// so pick the largest S with tiles*S <= 3 x 256.  Full chip: K=16384: 18.7 us (S=1) -> 12.5 us (S=3).
-// For batches that already fill the chip the 2-way split still wins by 5-12 % when it exists (its 256-register kernels
-// run two waves per SIMD; the unsplit kernel needs > 256 registers): K=1M: 319 us -> 285 us.
+// RNEA) for more wavefronts.  Measured on MI355X (iiwa-7 FD gradient, tools/exp_splits.py): it pays while the batch leaves
+// SIMDs idle, so pick the largest S with tiles*S <= 4 x 256 (one wave on every SIMD; the finer splits are compiled without
+// a register cap and a second wave on a SIMD would serialise behind the first).  K=16384: 17.7 us (S=1), 13.6 (S=2),
+// 12.4 (S=3), 11.5 (S=4), 18.3 (S=5).  For batches that already fill the chip the 2-way split still wins by 5-12 % when it
+// exists (its 256-register kernels run two waves per SIMD; the unsplit kernel needs > 256 registers): K=1M: 319 -> 285 us.
 static const int GRID_CUS = 256;   // MI355X
 static int available_splits(int alg, const int **list) {
     if (alg == GRID_ALG_FD_DU) { *list = G::FD_DU_SPLITS; return G::FD_DU_NUM_SPLITS; }
@@ -217,7 +217,7 @@ static int effective_split(const grid_handle *h, int alg, int K) {
     if (want > 1) { for (int i = 0; i < n; i++) if (list[i] == want) return want; return 1; }
     const int tiles = (K + G::GRID_WAVE_SIZE - 1) / G::GRID_WAVE_SIZE;
     int best = 1;
-    for (int i = 0; i < n; i++) if ((long long)tiles * list[i] <= 3LL * GRID_CUS && list[i] > best) best = list[i];
+    for (int i = 0; i < n; i++) if ((long long)tiles * list[i] <= 4LL * GRID_CUS && list[i] > best) best = list[i];
     if (best == 1 && G::NUM_JOINTS <= 12) { for (int i = 0; i < n; i++) if (list[i] == 2) best = 2; }
     return best;
 }

@@ -368,16 +368,28 @@ def core_gradient_columns(spec, ws, with_minv, prefetch=3):
 # ------------------------------------------------------------------------------------------------
 # single-kernel column-serial cores with RECOMPUTATION (large robots)
 # ------------------------------------------------------------------------------------------------
-def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False):
+def recompute_table_size(spec, kind, use_qdd=False, use_qdd_minv=False):
+    """Entries of the lane-private table of core_gradient_recompute(table=True): sin, cos, qd [, qdd] [, q if prismatic]."""
+    has_qdd = (kind == "fd") or use_qdd
+    return spec.n * (3 + (1 if has_qdd else 0) + (1 if any(not t for t in spec.uses_trig) else 0))
+
+
+def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table=False, facc_separate=True):
     """Column-serial gradient core that keeps almost nothing alive between columns: inside each column the velocities,
     accelerations and accumulated forces it needs (path root -> column joint, and the column's subtree) are RECOMPUTED
     from q, qd, qdd instead of being held in registers (the fused demand-ordered trace keeps 880-1160 values alive for
     Atlas-30 and spills) or parked in an HBM workspace (two-pass variant).  ~1.6x the arithmetic, no spills.
 
     kind "id": dc_du at (q, qd[, qdd]).  kind "fd": df_du; Minv and qdd are computed first (default) or read from the
-    inputs (use_qdd_minv: the reference's USE_QDD_MINV_FLAG variant; Minv entries are read where they are used)."""
+    inputs (use_qdd_minv: the reference's USE_QDD_MINV_FLAG variant; Minv entries are read where they are used).
+
+    table=True: sin q, cos q, qd, qdd are parked in a lane-private table after the prologue (tab_put) and re-loaded per
+    column (tab_get) instead of staying in ~4n registers for the whole kernel: with them resident the Atlas-30 kernels
+    spill 200-600 values to scratch, and once more than ~512 waves run the scratch lines no longer stay in L2 (measured:
+    dID 167 us at K=32768, 300 us at K=49152)."""
     n = spec.n
     tr = Tracer()
+    mark0 = tr.cse_mark()
     q = [tr.inp("in.q(%d)" % j) for j in range(n)]
     qd = [tr.inp("in.qd(%d)" % j) for j in range(n)]
     g = tr.inp("gravity")
@@ -402,11 +414,41 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False):
 
     memo = {}
     trig = list(trig)
+    if table:
+        slot = {"s": 0, "c": n, "qd": 2 * n}
+        nxt = 3 * n
+        if qdd is not None:
+            slot["qdd"] = nxt
+            nxt += n
+        if any(not t for t in spec.uses_trig):
+            slot["q"] = nxt
+            nxt += n
+        assert nxt == recompute_table_size(spec, kind, use_qdd, use_qdd_minv)
+        for j in range(n):
+            if trig[j] is not None:
+                tr.tab_put(slot["s"] + j, trig[j][0])
+                tr.tab_put(slot["c"] + j, trig[j][1])
+            elif "q" in slot:
+                tr.tab_put(slot["q"] + j, q[j])
+            tr.tab_put(slot["qd"] + j, qd[j])
+            if qdd is not None:
+                tr.tab_put(slot["qdd"] + j, qdd[j])
+        tr.fence()
+        tr.cse_release(mark0)       # nothing of the prologue is reused by name below (Minv entries are held by reference)
 
     def touch(j):
         # first use of joint j in this column: launder its inputs IN PLACE, so the chains recomputed below are new values
         # to the compiler (otherwise its CSE keeps the first column's v, a, f alive for all later columns and spills them)
-        if ("t", j) not in memo:
+        if ("t", j) not in memo and table:
+            memo[("t", j)] = True
+            if trig[j] is not None:
+                trig[j] = (tr.tab_get(slot["s"] + j), tr.tab_get(slot["c"] + j))
+            else:
+                q[j] = tr.tab_get(slot["q"] + j)
+            qd[j] = tr.tab_get(slot["qd"] + j)
+            if qdd is not None:
+                qdd[j] = tr.tab_get(slot["qdd"] + j)
+        elif ("t", j) not in memo:
             memo[("t", j)] = True
             q[j] = tr.launder(q[j])
             qd[j] = tr.launder(qd[j])
@@ -462,6 +504,20 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False):
         return memo[("f", j)]
 
     def loader(kind_, j):
+        if kind_ == "f" and table and facc_separate and spec.children[j]:
+            # the accumulated force of the column joint walks its whole subtree: do that on its own set of re-loaded
+            # inputs and forget the v, a it produced (they are recomputed at the visits that use them), otherwise up to
+            # 12 values per subtree joint stay alive from here to their visit
+            saved = dict(memo)
+            memo.clear()
+            f = facc(j)
+            memo.clear()
+            memo.update(saved)
+            for key in [key for key in memo if key[0] == "t"]:       # reload inputs for what follows
+                del memo[key]
+            for key in [key for key in memo if key[0] in ("X", "v", "xa", "a")]:
+                del memo[key]
+            return f
         return {"v": v_of, "xa": xa_of, "f": facc}[kind_](j)
 
     def minv_entry(r, k):

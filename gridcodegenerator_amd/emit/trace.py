@@ -315,6 +315,15 @@ class Tracer:
         self.outputs.append((dst_expr, val.ref))
         self.out_pos.append(len(self.nodes))       # creation-order emission places the store here
 
+    def tab_put(self, slot, val):
+        """Park a value in the lane-private table (LDS in the kernels, a local array in the _device functions)."""
+        self.out("tab:%d" % slot, val)
+
+    def tab_get(self, slot):
+        """Re-load a parked value: a fresh node per request, so its live range starts here."""
+        self._tab_serial = getattr(self, "_tab_serial", 0) + 1
+        return self.inp("in.tab_get(%d)/*%d*/" % (slot, self._tab_serial))
+
     def launder(self, a):
         """Same value, but opaque to the compiler from here on (an empty asm with the register as in/out operand): a later
         expression over the laundered value is NOT a common subexpression of the same expression over the original, so
@@ -542,7 +551,12 @@ class Tracer:
             if not live[k]:
                 continue
             op, a, b, c = self.nodes[k]
-            if op == "in":
+            if op == "in" and a.startswith("in.tab_get("):
+                slot = a[len("in.tab_get("):a.index(")")]
+                src = [r for (dst, r) in self.outputs if dst == "tab:" + slot]
+                assert len(src) == 1 and (isinstance(src[0], float) or abs(src[0]) < k), "table slot read before it was written"
+                val[k] = get(src[0]) + np.zeros(1)
+            elif op == "in":
                 val[k] = rnd(np.asarray(inputs[a], dtype=np.float64))
             elif op == "mul":
                 val[k] = rnd(get(a) * get(b))

@@ -90,7 +90,7 @@ class RuntimeEmitMixin:
         lay = self.io_layout[alg]
         need = [WAVE * nin for (_, nin) in lay["inputs"]]
         need.append(WAVE * lay["chunk"])
-        return max(need)
+        return max(need) + WAVE * lay.get("table", 0)       # staging region, then the lane-private table (if any)
 
     @staticmethod
     def _pad(x):
@@ -201,12 +201,31 @@ class RuntimeEmitMixin:
             "// ---- accessors the traced cores are written against ----",
             "template <typename T>",
             "struct grid_in_ptrs {",
-            "    const T *q_; const T *qd_; const T *u_; const T *qdd_; const T *Minv_;",
+            "    const T *q_; const T *qd_; const T *u_; const T *qdd_; const T *Minv_; T *tab_;",
             "    __host__ __device__ __forceinline__ T q(int i) const {return q_[i];}",
             "    __host__ __device__ __forceinline__ T qd(int i) const {return qd_[i];}",
             "    __host__ __device__ __forceinline__ T u(int i) const {return u_[i];}",
             "    __host__ __device__ __forceinline__ T qdd(int i) const {return qdd_[i];}",
             "    __host__ __device__ __forceinline__ T Minv(int i) const {return Minv_[i];}",
+            "    // lane-private table of the recomputing gradient cores (a plain local array behind this accessor)",
+            "    __host__ __device__ __forceinline__ void tab_put(int i, T v) const {tab_[i] = v;}",
+            "    __host__ __device__ __forceinline__ T tab_get(int i) const {return tab_[i];}",
+            "};",
+            "// the same inputs plus a per-wave LDS table: entry i of lane l lives at i*64 + l (conflict-free).  The kernels of large",
+            "// robots park sin q, cos q, qd, qdd there after the prologue and re-load them per gradient column, so that ~4n",
+            "// registers are not held for the whole kernel.  Every read goes through a laundered copy of the lane index: hipcc would",
+            "// otherwise merge the re-loads of one entry into a single long-lived value (and spill it); a volatile read would do",
+            "// too but is compiled to flat_load (address-space inference skips volatile accesses).",
+            "template <typename T>",
+            "struct grid_in_lds {",
+            "    const T *q_; const T *qd_; const T *u_; const T *qdd_; const T *Minv_; T *tab_wave_; int lane_;",
+            "    __device__ __forceinline__ T q(int i) const {return q_[i];}",
+            "    __device__ __forceinline__ T qd(int i) const {return qd_[i];}",
+            "    __device__ __forceinline__ T u(int i) const {return u_[i];}",
+            "    __device__ __forceinline__ T qdd(int i) const {return qdd_[i];}",
+            "    __device__ __forceinline__ T Minv(int i) const {return Minv_[i];}",
+            "    __device__ __forceinline__ void tab_put(int i, T v) const {tab_wave_[i*GRID_WAVE_SIZE + lane_] = v;}",
+            "    __device__ __forceinline__ T tab_get(int i) const {int l = lane_; asm volatile(\"\" : \"+v\"(l)); return tab_wave_[i*GRID_WAVE_SIZE + l];}",
             "};",
             "// accessors of the two-pass (pipeline) kernels: the per-tile workspace is SoA, value `slot` of lane l at slot*64 + l",
             "template <typename T>",

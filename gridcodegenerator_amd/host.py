@@ -97,16 +97,28 @@ def build_library(robot_name, precision="fp32", force=False, verbose=False, extr
 
 
 # generator options used when a built-in robot is built without explicit options (tests rely on these)
-DEFAULT_GEN_KWARGS = {"mixed5": {"pipeline": True}}   # the small test robot also exercises the two-pass kernels
+DEFAULT_GEN_KWARGS = {"mixed5": {"pipeline": True, "grad_schedule": "recompute", "grad_table": True}}   # the small test robot exercises the two-pass kernels and the recomputing (LDS table) schedule, prismatic joints included
 
 
 def _build_library_locked(robot_name, precision, force, verbose, extra_flags, gen_kwargs):
     if not gen_kwargs:
         gen_kwargs = dict(DEFAULT_GEN_KWARGS.get(robot_name, {}))
     p = library_paths(robot_name, precision)
-    # -O1 for large robots: their kernels are single basic blocks of 50-70 k instructions that the generator has already
-    # scheduled; at -O3 hipcc needs 4-20 minutes per kernel and the result is 15 % SLOWER (Atlas-30 dID 372 vs 306 us)
-    opt = "-O1" if get_robot(robot_name).get_num_joints() > 12 else "-O3"
+    # Optimisation level per translation unit.  Small robots: -O3 everywhere.  Large robots (n > 12): their gradient kernels
+    # are single basic blocks of 50-70 k instructions that the generator has already scheduled; hipcc needs 4-20 minutes
+    # for one at -O2/-O3 and the result is not faster (Atlas-30 dID, K = 65536: 372 us at -O3, 306-359 us at -O1).
+    # RNEA and FD are fastest at -O3 (seconds to compile), Minv at -O1 (65 vs 85 us).
+    large = get_robot(robot_name).get_num_joints() > 12
+    opt = "-O3"
+
+    def kernel_opt(decl):
+        if not large:
+            return "-O3"
+        name = decl.split("::")[1].split("<")[0]
+        if name in ("inverse_dynamics_kernel", "forward_dynamics_kernel"):
+            return "-O3"
+        return "-O1"
+
     flags = ["--offload-arch=" + ARCH, opt, "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-I" + INCLUDE_DIR] + list(extra_flags)
     # (no absolute paths in the fingerprint: the same tree is mounted at different locations on different boxes)
     fp = _source_fingerprint(repr(sorted(gen_kwargs.items())) + precision + " ".join(f for f in flags if not f.startswith("-I")))
@@ -125,7 +137,9 @@ def _build_library_locked(robot_name, precision, force, verbose, extra_flags, ge
     os.makedirs(objdir, exist_ok=True)
     jobs = [("capi", common + ["-DGRID_EXTERN_KERNELS", CSRC, "-o", os.path.join(objdir, "capi.o")])]
     for k in range(len(gen.kernel_instances)):
-        jobs.append(("kernel%d" % k, common + ["-DGRID_INST=%d" % k, KERNEL_INST_SRC, "-o", os.path.join(objdir, "kernel%d.o" % k)]))
+        kflags = [kernel_opt(gen.kernel_instances[k]) if f == opt else f for f in common]
+        jobs.append(("kernel%d" % k, kflags + ["-DGRID_INST=%d" % k, KERNEL_INST_SRC, "-o", os.path.join(objdir, "kernel%d.o" % k)]))
+    jobs.sort(key=lambda j: {"-O2": 0, "-O3": 1}.get(next((f for f in j[1] if f in ("-O1", "-O2", "-O3")), "-O3"), 2) if large else 0)   # longest first
     # per-object cache: an object is reused when the generated header, its own source and the flags are unchanged (a C-ABI
     # edit then recompiles capi.o only -- the largest Atlas-30 kernel alone takes ~20 minutes)
     with open(p["header"], "rb") as fh:

@@ -10,8 +10,12 @@
 #define STR(s) #s
 
 template <int BODY16>   // straight-line block = BODY16 * 16 instructions
-__global__ __launch_bounds__(64) void k(float *out, float a, float b, int reps) {
+__global__ __launch_bounds__(64) void k(float *out, float a, float b, int reps, int desync) {
     float x[16];
+    if (desync) {   // start the waves of a CU at different times: they then stream different parts of the code
+        const unsigned d = ((blockIdx.x * 2654435761u) >> 13) % 8u;
+        for (unsigned i = 0; i < d * (unsigned)desync; i++) __builtin_amdgcn_s_sleep(127);
+    }
 #pragma unroll
     for (int i = 0; i < 16; i++) x[i] = threadIdx.x * 0.001f + i;
     for (int it = 0; it < (BODY16 > 512 ? 1 : reps); it++) {
@@ -32,19 +36,19 @@ __global__ __launch_bounds__(64) void k(float *out, float a, float b, int reps) 
 }
 
 template <int BODY16>
-int run(float *d_out, int total16) {
+int run(float *d_out, int total16, int desync = 0) {
     const int reps = BODY16 > 512 ? 1 : total16 / BODY16;      // bodies > 64 KB: executed once (s_cbranch reaches +-128 KB)
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     for (int wps = 1; wps <= 4; wps *= 2) {
         const int blocks = 1024 * wps;
-        k<BODY16><<<blocks, 64>>>(d_out, 1.0001f, 0.5f, reps);
+        k<BODY16><<<blocks, 64>>>(d_out, 1.0001f, 0.5f, reps, desync);
         CHECK(hipDeviceSynchronize());
         CHECK(hipEventRecord(e0));
-        k<BODY16><<<blocks, 64>>>(d_out, 1.0001f, 0.5f, reps);
+        k<BODY16><<<blocks, 64>>>(d_out, 1.0001f, 0.5f, reps, desync);
         CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
         const double ninst = 16.0 * BODY16 * reps;
-        printf("code %7d B  waves/SIMD %d  %8.1f us  %.3f ns/instr/wave (%.2f cycles @2.4GHz)  SIMD issue interval %.2f cycles\n", BODY16 * 16 * 8, wps, ms * 1e3,
+        printf("desync %d  code %7d B  waves/SIMD %d  %8.1f us  %.3f ns/instr/wave (%.2f cycles @2.4GHz)  SIMD issue interval %.2f cycles\n", desync, BODY16 * 16 * 8, wps, ms * 1e3,
                ms * 1e6 / ninst, ms * 1e6 / ninst * 2.4, ms * 1e6 / ninst * 2.4 / wps);
     }
     return 0;
@@ -59,5 +63,9 @@ int main() {
     if (run<1024>(d_out, total16)) return 1;    // 128 KB
     if (run<4096>(d_out, total16)) return 1;    // 512 KB
     if (run<8192>(d_out, total16)) return 1;    //   1 MB, executed once
+    // desynchronised: wave w of a CU starts (hash % 8) * 6 * 3.4 us late (64 KB of code is ~17 us of execution)
+    if (run<256>(d_out, total16, 6)) return 1;
+    if (run<4096>(d_out, total16, 6)) return 1;
+    if (run<8192>(d_out, total16, 6)) return 1;
     return 0;
 }
