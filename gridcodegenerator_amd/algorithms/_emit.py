@@ -137,7 +137,7 @@ class AlgorithmEmitMixin:
         self.gen_add_code_line("template <typename T, typename C = typename grid_compute<T>::type>")
         # the 2-way split is the one used when the batch fills the chip: cap it at 256 registers so two waves share a SIMD
         # (2nd argument = waves per SIMD).  Finer splits only run when there are fewer waves than SIMDs: no cap, no spills.
-        occ = 2 if (parts and len(parts) == 2) else self.waves_per_simd
+        occ = 2 if (parts and (len(parts) == 2 or self.grad_schedule == "recompute")) else self.waves_per_simd
         self.gen_add_code_line("__global__ __launch_bounds__(GRID_MAX_THREADS%s)" % (", %d" % occ if occ > 1 else ""))
         self.gen_add_code_line(sig + " {", True)
         self.gen_add_code_lines([
@@ -182,7 +182,7 @@ class AlgorithmEmitMixin:
             self.gen_add_code_line("switch (it.part){", True)
             for pi, (pcore, cols) in enumerate(parts):
                 len0 = n * len(cols)
-                ch = self._chunk_for(len0)
+                ch = chunk or self._chunk_for(len0)
                 assert 64 * ch <= self.lds_per_wave(alg)
                 self.gen_add_code_line("case %d: {" % pi, True)
                 if direct:
@@ -304,6 +304,18 @@ class AlgorithmEmitMixin:
         self.gen_add_code_line("void %s_pipeline_launch(T *, const T *, const int, const T *, T *, const robotModel<T> *, const T, const int, dim3, dim3, hipStream_t) {}" % base)
         self.gen_add_code_line("")
 
+    def _split_builder(self, kind):
+        """cols -> traced core of a column group.  Recomputing schedule (large robots): every group recomputes only what its
+        own columns need, so splitting costs no repeated prefix for dID; dFD keeps the fused builder (Minv is a shared prefix)."""
+        if kind == "id" and self.grad_schedule == "recompute":
+            def build(cols):
+                return cores.core_gradient_recompute(self.spec, "id", cols=cols)
+            build.recompute = True
+            return build
+        if kind == "id":
+            return lambda cols: cores.core_inverse_dynamics_gradient(self.spec, False, cols)
+        return lambda cols: cores.core_forward_dynamics_gradient(self.spec, False, cols)
+
     def _choose_splits(self, builder):
         """Column-split variants worth emitting: [(S, parts, worst part's op count)], each step improving >= 3 %."""
         n = self.spec.n
@@ -312,7 +324,7 @@ class AlgorithmEmitMixin:
             # compile and were slower than the unsplit kernel (profiles/r01/sweep_atlas30_split.txt): none by default
             # small robots: 2 (full chip, two waves per SIMD), 3 and 4 (K = 16384 is 256 tiles: 4 x 256 = one wave on every
             # SIMD of an MI355X, measured best: 11.5 us vs 12.4 (S=3) vs 17.7 (S=1)) and one column per block for tiny batches
-            cand = sorted(set([2, 3, 4, n])) if n <= 8 else ([2, 4] if n <= 12 else [])
+            cand = sorted(set([2, 3, 4, n])) if n <= 8 else ([2, 4] if (n <= 12 or getattr(builder, "recompute", False)) else [])
             limit = 4
         else:
             cand = [int(S) for S in self.grad_splits]
@@ -345,11 +357,12 @@ class AlgorithmEmitMixin:
             named = []
             for pi, cols in enumerate(parts):
                 cname = "%s_s%dp%d" % (core_base, S, pi)
+                rec = getattr(builder, "recompute", False)
                 self._emit_core(cname, "%s: column group %d of %d (columns %d..%d of d/dq and of d/dqd)"
-                                % (doc, pi, S, cols[0], cols[-1]), builder(cols))
+                                % (doc, pi, S, cols[0], cols[-1]), builder(cols), order="creation" if rec else None)
                 named.append((cname, cols))
             self._emit_kernel(alg, "%s_split%d" % (kernel_base, S), None, doc + " (column-split x%d)" % S, out_name,
-                              primary, [], has_gravity, accessor, parts=named)
+                              primary, [], has_gravity, accessor, parts=named, chunk=self.spec.n if rec else None)
         # launcher
         pname, pcount, pstride = primary
         grav = "const T gravity, " if has_gravity else ""
@@ -735,7 +748,7 @@ class AlgorithmEmitMixin:
         self._emit_split_family("ID_DU", "inverse_dynamics_gradient_kernel", "inverse_dynamics_gradient_core",
                                 "Computes the gradient of inverse dynamics", "dc_du", ("q_qd", 2 * n, "stride_q_qd"), True,
                                 "s_q_qd, s_q_qd + %d, nullptr, nullptr, nullptr" % n,
-                                lambda cols: cores.core_inverse_dynamics_gradient(self.spec, False, cols), None)
+                                self._split_builder("id"), None)
         if self.use_pipeline:
             self._emit_pipeline_family("ID_DU", "inverse_dynamics_gradient", "Computes the gradient of inverse dynamics", "dc_du",
                                        ("q_qd", 2 * n, "stride_q_qd"), True)

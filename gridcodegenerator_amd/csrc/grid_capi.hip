@@ -217,6 +217,10 @@ static int effective_split(const grid_handle *h, int alg, int K) {
     if (want > 1) { for (int i = 0; i < n; i++) if (list[i] == want) return want; return 1; }
     const int tiles = (K + G::GRID_WAVE_SIZE - 1) / G::GRID_WAVE_SIZE;
     int best = 1;
+    // large robots: the column groups are register-capped and spill, and from K = 32768 on the 7.2 KB-per-configuration output
+    // stream is what bounds the kernel: split only while there is at most one tile per CU (Atlas-30 dID, K=16384: 163 us
+    // unsplit, 119 us S=2, 100 us S=4; K=32768: 179 vs 218 us)
+    if (G::NUM_JOINTS > 12 && tiles > GRID_CUS) return 1;
     for (int i = 0; i < n; i++) if ((long long)tiles * list[i] <= 4LL * GRID_CUS && list[i] > best) best = list[i];
     if (best == 1 && G::NUM_JOINTS <= 12) { for (int i = 0; i < n; i++) if (list[i] == 2) best = 2; }
     return best;

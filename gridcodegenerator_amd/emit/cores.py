@@ -374,7 +374,7 @@ def recompute_table_size(spec, kind, use_qdd=False, use_qdd_minv=False):
     return spec.n * (3 + (1 if has_qdd else 0) + (1 if any(not t for t in spec.uses_trig) else 0))
 
 
-def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table=False, facc_separate=True):
+def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table=False, facc_separate=True, cols=None):
     """Column-serial gradient core that keeps almost nothing alive between columns: inside each column the velocities,
     accelerations and accumulated forces it needs (path root -> column joint, and the column's subtree) are RECOMPUTED
     from q, qd, qdd instead of being held in registers (the fused demand-ordered trace keeps 880-1160 values alive for
@@ -526,6 +526,13 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
             return None
         return Minv[a][b] if Minv is not None else tr.inp("in.Minv(%d)" % (n * b + a))
 
+    # cols = [c0..c1] (column-split kernels): only those columns, written at LOCAL indices -- d/dq columns at n*(col-c0),
+    # d/dqd columns at n*len(cols) + n*(col-c0); the kernel sink maps the two runs back (see _out_grad)
+    if cols is not None:
+        assert list(cols) == list(range(cols[0], cols[-1] + 1))
+    lo_base = (lambda col: n * col) if cols is None else (lambda col: n * (col - cols[0]))
+    hi_off = n * n if cols is None else n * len(cols)
+
     def emit_column(col, dc):
         memo.clear()
         rows = sorted(dc)
@@ -533,17 +540,17 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
             for half in (0, 1):
                 for r in range(n):
                     e = dc.get(r)
-                    tr.out(half * n * n + n * col + r, e[half] if e is not None else tr.zero())
+                    tr.out(half * hi_off + lo_base(col) + r, e[half] if e is not None else tr.zero())
             return
         hi = []
         for r in range(n):
             m = [(k, minv_entry(r, k)) for k in rows]
             m = [(k, e) for (k, e) in m if e is not None]
-            tr.out(n * col + r, -tr.dot([(e, dc[k][0]) for (k, e) in m]))
+            tr.out(lo_base(col) + r, -tr.dot([(e, dc[k][0]) for (k, e) in m]))
             hi.append(-tr.dot([(e, dc[k][1]) for (k, e) in m]))
         for r in range(n):
-            tr.out(n * n + n * col + r, hi[r])
+            tr.out(hi_off + lo_base(col) + r, hi[r])
 
     keep = ([t.ref for row in Minv for t in row if t is not None] if Minv is not None else [])
-    alg.rnea_grad_columns(tr, spec, I, q, qd, trig, loader, emit_column, prefetch=0, xof=Xof, keep=keep)
+    alg.rnea_grad_columns(tr, spec, I, q, qd, trig, loader, emit_column, order=cols, prefetch=0, xof=Xof, keep=keep)
     return tr

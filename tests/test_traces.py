@@ -181,3 +181,36 @@ def test_recompute_cores(robot_name, setup, variant):
     got = _scatter(tr, _run(tr, inputs), 2 * n * n)
     assert relerr(got, ref)[0] < 1e-12
     assert tr.op_counts().get("lnd", 0) > 0      # inputs are laundered per column (keeps hipcc from undoing the recomputation)
+
+
+@pytest.mark.parametrize("variant", ["id", "fd", "fd_qdd_minv"])
+def test_recompute_cores_with_table_and_column_groups(robot_name, setup, variant):
+    """Options of the recomputing schedule: inputs parked in the lane-private table (tab_put / tab_get, resolved by the IR
+    interpreter) and column groups written at local indices (the column-split kernels of large robots)."""
+    spec, T, q, qd, u = setup(robot_name)
+    n = spec.n
+    ref_fd, parts = O.fd_grad(T, q, qd, u, return_parts=True)
+    if variant == "id":
+        kw, inputs, ref = dict(kind="id"), _inputs(n, q, qd), O.rnea_grad(T, q, qd, None)
+    elif variant == "fd":
+        kw, inputs, ref = dict(kind="fd"), _inputs(n, q, qd, u=u), ref_fd
+    else:
+        kw = dict(kind="fd", use_qdd_minv=True)
+        inputs, ref = _inputs(n, q, qd, qdd=parts["qdd"], Minv_flat=O.flat_colmajor(np.triu(parts["Minv"]))), ref_fd
+    tr = cores.core_gradient_recompute(spec, table=True, **kw)
+    outs = _run(tr, inputs)
+    got = np.zeros((K, 2 * n * n))
+    ntab = 0
+    for (dst, _), col in zip(tr.outputs, outs.T):
+        if isinstance(dst, str):
+            ntab += 1
+        else:
+            got[:, dst] = col
+    assert ntab > 0 and ntab <= cores.recompute_table_size(spec, kw["kind"], use_qdd=True)
+    assert relerr(got, _grad_flat(ref, n))[0] < 1e-12
+    # a column group: d/dq columns first, then d/dqd, at local indices
+    cols = list(range(n // 3, 2 * n // 3 + 1))
+    trc = cores.core_gradient_recompute(spec, cols=cols, **kw)
+    gotc = _scatter(trc, _run(trc, inputs), 2 * n * len(cols))
+    want = np.concatenate([ref[:, :, c] for c in cols] + [ref[:, :, n + c] for c in cols], axis=1)
+    assert relerr(gotc, want)[0] < 1e-12
