@@ -324,7 +324,10 @@ class AlgorithmEmitMixin:
             # compile and were slower than the unsplit kernel (profiles/r01/sweep_atlas30_split.txt): none by default
             # small robots: 2 (full chip, two waves per SIMD), 3 and 4 (K = 16384 is 256 tiles: 4 x 256 = one wave on every
             # SIMD of an MI355X, measured best: 11.5 us vs 12.4 (S=3) vs 17.7 (S=1)) and one column per block for tiny batches
-            cand = sorted(set([2, 3, 4, n])) if n <= 8 else ([2, 4] if (n <= 12 or getattr(builder, "recompute", False)) else [])
+            # large robots: none.  Column groups of the recomputing dID were built and measured (Atlas-30, K=16384: 163 us
+            # unsplit, 119 us S=2, 100 us S=4) but they have to be register-capped to share a SIMD, spill ~1000 values and
+            # 190 SGPRs, and one build of them faulted on the GPU -- not shipped.
+            cand = sorted(set([2, 3, 4, n])) if n <= 8 else ([2, 4] if n <= 12 else [])
             limit = 4
         else:
             cand = [int(S) for S in self.grad_splits]

@@ -359,8 +359,24 @@ class RuntimeEmitMixin:
             "            // partially unrolled on purpose: 8 LDS reads in flight, small code (full unrolling made the Atlas kernels",
             "            // take 7-25 minutes to compile)",
             "            if (nvalid == GRID_WAVE_SIZE){   // full tile: no per-iteration predicate",
-            "                #pragma unroll 8",
-            "                for (int t = 0; t < GRID_WAVE_SIZE/G; t++){dst[(unsigned)(t*G*ROW)] = src[t*G*LEN];}",
+            "                constexpr int NIT = GRID_WAVE_SIZE/G;",
+            "                if constexpr (NIT % 8 == 0){",
+            "                    // groups of 8 written out by hand (8 LDS reads in flight, then 8 stores) so that the shape does not",
+            "                    // depend on the optimisation level (-O1 keeps a `#pragma unroll` loop rolled: one LDS round trip per",
+            "                    // element).  Addresses stay per-lane 64-bit VGPR pointers + constants: a wave-uniform SGPR base inside",
+            "                    // this divergent region faulted on the register-capped Atlas kernels (190 SGPR spills).",
+            "                    for (int t = 0; t < NIT; t += 8){",
+            "                        const T *s = src + t*G*LEN; T *d = dst + (size_t)t*(G*ROW);",
+            "                        const T a0 = s[0*G*LEN], a1 = s[1*G*LEN], a2 = s[2*G*LEN], a3 = s[3*G*LEN];",
+            "                        const T a4 = s[4*G*LEN], a5 = s[5*G*LEN], a6 = s[6*G*LEN], a7 = s[7*G*LEN];",
+            "                        d[0*G*ROW] = a0; d[1*G*ROW] = a1; d[2*G*ROW] = a2; d[3*G*ROW] = a3;",
+            "                        d[4*G*ROW] = a4; d[5*G*ROW] = a5; d[6*G*ROW] = a6; d[7*G*ROW] = a7;",
+            "                    }",
+            "                }",
+            "                else {",
+            "                    #pragma unroll",
+            "                    for (int t = 0; t < NIT; t++){dst[(unsigned)(t*G*ROW)] = src[t*G*LEN];}",
+            "                }",
             "            }",
             "            else {",
             "                #pragma unroll 2",
