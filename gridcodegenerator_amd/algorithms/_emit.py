@@ -137,7 +137,7 @@ class AlgorithmEmitMixin:
         self.gen_add_code_line("template <typename T, typename C = typename grid_compute<T>::type>")
         # the 2-way split is the one used when the batch fills the chip: cap it at 256 registers so two waves share a SIMD
         # (2nd argument = waves per SIMD).  Finer splits only run when there are fewer waves than SIMDs: no cap, no spills.
-        occ = 2 if (parts and (len(parts) == 2 or self.grad_schedule == "recompute")) else self.waves_per_simd
+        occ = 2 if (parts and len(parts) == 2 and n <= 12) else self.waves_per_simd
         self.gen_add_code_line("__global__ __launch_bounds__(GRID_MAX_THREADS%s)" % (", %d" % occ if occ > 1 else ""))
         self.gen_add_code_line(sig + " {", True)
         self.gen_add_code_lines([
@@ -312,6 +312,11 @@ class AlgorithmEmitMixin:
                 return cores.core_gradient_recompute(self.spec, "id", cols=cols)
             build.recompute = True
             return build
+        if kind == "fd" and self.grad_schedule == "recompute" and self.spec.n > 12:
+            def build_fd(cols):
+                return cores.core_gradient_recompute(self.spec, "fd", cols=cols)
+            build_fd.recompute = True
+            return build_fd
         if kind == "id":
             return lambda cols: cores.core_inverse_dynamics_gradient(self.spec, False, cols)
         return lambda cols: cores.core_forward_dynamics_gradient(self.spec, False, cols)
@@ -320,14 +325,13 @@ class AlgorithmEmitMixin:
         """Column-split variants worth emitting: [(S, parts, worst part's op count)], each step improving >= 3 %."""
         n = self.spec.n
         if self.grad_splits == "auto":
-            # large robots: the split kernels need > 256 registers per column group, spill, take 10-25 minutes each to
-            # compile and were slower than the unsplit kernel (profiles/r01/sweep_atlas30_split.txt): none by default
+            # large robots with the FUSED schedule: the split kernels need > 256 registers per column group, spill, take
+            # 10-25 minutes each to compile and were slower than the unsplit kernel (profiles/r01/sweep_atlas30_split.txt)
             # small robots: 2 (full chip, two waves per SIMD), 3 and 4 (K = 16384 is 256 tiles: 4 x 256 = one wave on every
-            # SIMD of an MI355X, measured best: 11.5 us vs 12.4 (S=3) vs 17.7 (S=1)) and one column per block for tiny batches
-            # large robots: none.  Column groups of the recomputing dID were built and measured (Atlas-30, K=16384: 163 us
-            # unsplit, 119 us S=2, 100 us S=4) but they have to be register-capped to share a SIMD, spill ~1000 values and
-            # 190 SGPRs, and one build of them faulted on the GPU -- not shipped.
-            cand = sorted(set([2, 3, 4, n])) if n <= 8 else ([2, 4] if n <= 12 else [])
+            # SIMD of an MI355X, measured best: 11.5 us vs 12.4 (S=3) vs 17.7 (S=1)) and one column per block for tiny batches.
+            # Large robots with the recomputing schedule: 2 and 4, NOT register-capped (a capped build of them spilled ~1000
+            # values and faulted); they serve batches of <= 256 / 512 tiles (Atlas-30 at K = 16384 is one wave per CU).
+            cand = sorted(set([2, 3, 4, n])) if n <= 8 else ([2, 4] if (n <= 12 or getattr(builder, "recompute", False)) else [])
             limit = 4
         else:
             cand = [int(S) for S in self.grad_splits]
@@ -342,7 +346,7 @@ class AlgorithmEmitMixin:
             parts, est = cores.balanced_column_split(self.spec, S, cost)
             if len(parts) != S or any(not c for c in parts):
                 continue
-            if self.grad_splits != "auto" or n <= 8 or est < 0.97 * last:
+            if self.grad_splits != "auto" or n <= 8 or getattr(builder, "recompute", False) or est < 0.97 * last:
                 picked.append((S, parts, est))
                 last = est
         if self.grad_splits == "auto" and len(picked) > limit > 1:      # keep the coarsest, the finest and spread the rest
@@ -841,7 +845,7 @@ class AlgorithmEmitMixin:
         self._emit_split_family("FD_DU", "forward_dynamics_gradient_kernel", "forward_dynamics_gradient_core",
                                 "Computes the gradient of forward dynamics", "df_du", ("q_qd_u", 3 * n, "stride_q_qd_u"), True,
                                 "s_q_qd_u, s_q_qd_u + %d, s_q_qd_u + %d, nullptr, nullptr" % (n, 2 * n),
-                                lambda cols: cores.core_forward_dynamics_gradient(self.spec, False, cols), None)
+                                self._split_builder("fd"), None)
         if self.use_pipeline:
             self._emit_pipeline_family("FD_DU", "forward_dynamics_gradient", "Computes the gradient of forward dynamics", "df_du",
                                        ("q_qd_u", 3 * n, "stride_q_qd_u"), False)

@@ -217,10 +217,11 @@ static int effective_split(const grid_handle *h, int alg, int K) {
     if (want > 1) { for (int i = 0; i < n; i++) if (list[i] == want) return want; return 1; }
     const int tiles = (K + G::GRID_WAVE_SIZE - 1) / G::GRID_WAVE_SIZE;
     int best = 1;
-    // large robots: the column groups are register-capped and spill, and from K = 32768 on the 7.2 KB-per-configuration output
-    // stream is what bounds the kernel: split only while there is at most one tile per CU (Atlas-30 dID, K=16384: 163 us
-    // unsplit, 119 us S=2, 100 us S=4; K=32768: 179 vs 218 us)
-    if (G::NUM_JOINTS > 12 && tiles > GRID_CUS) return 1;
+    // large robots: same rule (their column groups are not register-capped: one wave per SIMD); there is no 2-way fallback for
+    // full-chip batches because nothing can share a SIMD with a 512-register wave.  Atlas-30, K=16384: dID 160 -> 76 us,
+    // dFD 261 -> 185 us (S=4); K=32768 (S=2): dID 186 -> 110 us but dFD 320 -> 353 us (every group repeats Minv and the
+    // 236 MB output stream is already the larger cost), so dFD only splits up to one tile per CU
+    if (G::NUM_JOINTS > 12 && alg == GRID_ALG_FD_DU && tiles > GRID_CUS) return 1;
     for (int i = 0; i < n; i++) if ((long long)tiles * list[i] <= 4LL * GRID_CUS && list[i] > best) best = list[i];
     if (best == 1 && G::NUM_JOINTS <= 12) { for (int i = 0; i < n; i++) if (list[i] == 2) best = 2; }
     return best;
