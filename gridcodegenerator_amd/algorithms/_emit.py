@@ -199,6 +199,49 @@ class AlgorithmEmitMixin:
             self.gen_add_end_control_flow()
         self.gen_add_end_control_flow()
         self.gen_add_end_function()
+        if not parts:
+            self._emit_kernel_single_timing(alg, name, core, doc, out_name, primary, extras, has_gravity, accessor)
+
+    def _emit_kernel_single_timing(self, alg, name, core, doc, out_name, primary, extras, has_gravity, accessor):
+        """Latency twin of a kernel (reference: gen_*_kernel(..., single_call_timing=True), e.g.
+        _forward_dynamics_gradient.py:129-131,162-176): same argument list, NUM_TIMESTEPS is the number of REPETITIONS;
+        every lane evaluates configuration 0 that many times in a row and one lane writes the result row.  The inputs
+        are laundered before every repetition so the compiler can neither hoist nor merge the evaluations.  Not part of
+        the explicit-instantiation list: instantiated by whoever calls the *_single_timing host wrapper."""
+        n_out = self.io_layout[alg]["n_out"]
+        pname, pcount, pstride = primary
+        sig = "void %s_single_timing(T *d_%s, const T *d_%s, const int %s, " % (name, out_name, pname, pstride)
+        for (ename, _) in extras:
+            sig += "const T *d_%s, " % ename
+        sig += "const robotModel<T> *d_robotModel, " + ("const T gravity, " if has_gravity else "") + "const int NUM_TIMESTEPS)"
+        self.gen_add_func_doc(doc + " -- single-configuration latency twin",
+                              ["NUM_TIMESTEPS is overloaded as the number of timing repetitions (as in the reference)",
+                               "every lane of the launch evaluates configuration 0; lane 0 of block 0 writes d_%s[0..%d)" % (out_name, n_out)],
+                              [], None)
+        self.gen_add_code_line("template <typename T, typename C = typename grid_compute<T>::type>")
+        self.gen_add_code_line("__global__ __launch_bounds__(GRID_MAX_THREADS)")
+        self.gen_add_code_line(sig + " {", True)
+        self.gen_add_code_line("(void)%s; (void)d_robotModel;" % pstride)
+        arrays = [(pname, pcount)] + [(en, ec) for (en, ec) in extras if ec <= MAX_IN_PIECE]
+        for (an, ac) in arrays:
+            self.gen_add_code_line("T s_%s[%d];" % (an, ac))
+            for i0 in range(0, ac, 8):
+                self.gen_add_code_line(" ".join("s_%s[%d] = d_%s[%d];" % (an, i, an, i) for i in range(i0, min(ac, i0 + 8))))
+        for (en, ec) in extras:
+            if ec > MAX_IN_PIECE:
+                self.gen_add_code_line("const T *s_%s = d_%s;" % (en, en))
+        table = self.io_layout[alg].get("table", 0)
+        if table:
+            self.gen_add_code_line("T s_tab[%d];" % table)
+        self.gen_add_code_line("const grid_in_ptrs<T> in = {%s%s};" % (accessor, ", s_tab" if table else ""))
+        self.gen_add_code_line("grid_out_first<T> out = {d_%s, blockIdx.x == 0 && threadIdx.x == 0};" % out_name)
+        self.gen_add_code_line("for (int rep = 0; rep < NUM_TIMESTEPS; rep++){", True)
+        for (an, ac) in arrays:
+            for i0 in range(0, ac, 8):
+                self.gen_add_code_line(" ".join("GRID_LAUNDER(s_%s[%d]);" % (an, i) for i in range(i0, min(ac, i0 + 8))))
+        self.gen_add_code_line("%s<T,C>(in, out, %s);" % (core, "gravity" if has_gravity else "static_cast<T>(0)"))
+        self.gen_add_end_control_flow()
+        self.gen_add_end_function()
 
     def _emit_pipeline_family(self, alg, base, doc, out_name, primary, has_qdd_variant):
         """Two-pass variant of a gradient kernel for robots whose working set exceeds the register file:
@@ -399,10 +442,12 @@ class AlgorithmEmitMixin:
         """Host wrappers: mode 0 (copies + launch, reference semantics), _compute_only (mode 2) and an
         asynchronous _launch extension (explicit stream, no synchronisation) used by the C-ABI shim."""
         grav = "const T gravity, " if has_gravity else ""
-        for mode in ("full", "compute_only", "launch"):
-            suffix = {"full": "", "compute_only": "_compute_only", "launch": "_launch"}[mode]
-            tail = {"full": ", hipStream_t *streams", "compute_only": "", "launch": ", hipStream_t stream"}[mode]
+        for mode in ("full", "single_timing", "compute_only", "launch"):
+            suffix = {"full": "", "single_timing": "_single_timing", "compute_only": "_compute_only", "launch": "_launch"}[mode]
+            tail = {"full": ", hipStream_t *streams", "single_timing": ", hipStream_t *streams", "compute_only": "", "launch": ", hipStream_t stream"}[mode]
             notes = {"full": ["H2D copy of the inputs, kernel, D2H copy of the result, synchronous (reference mode 0)"],
+                     "single_timing": ["reference mode 1: ONE configuration (the first of the host buffers) evaluated num_timesteps times inside",
+                                       "the *_kernel_single_timing twin, wall-clock per repetition printed as `Single Call %s`" % timing_label],
                      "compute_only": ["inputs/outputs already on the device (reference mode 2: _compute_only), synchronous"],
                      "launch": ["MI355X extension: asynchronous launch on `stream`, no copies, no synchronisation",
                                 "(graph-capturable; used by the C-ABI and for multi-GPU sharding on independent streams)"]}[mode]
@@ -414,22 +459,32 @@ class AlgorithmEmitMixin:
             self.gen_add_code_line("__host__")
             self.gen_add_code_line("void %s%s(gridData<T> *hd_data, const robotModel<T> *d_robotModel, %sconst int num_timesteps," % (name, suffix, grav))
             self.gen_add_code_line("        const dim3 block_dimms, const dim3 thread_dimms%s) {" % tail, True)
-            self.gen_add_code_line("dim3 blocks, threads; grid_launch_dims(block_dimms, thread_dimms, num_timesteps, &blocks, &threads);")
+            single = (mode == "single_timing")
+            one = (lambda line: line.replace("*num_timesteps*sizeof(T)", "*sizeof(T)")) if single else (lambda line: line)
+            self.gen_add_code_line("dim3 blocks, threads; grid_launch_dims(block_dimms, thread_dimms, %s, &blocks, &threads);"
+                                   % ("1" if single else "num_timesteps"))
             self.gen_add_code_line("const size_t lds_bytes = grid_lds_bytes<T>(threads, %d);" % self.lds_per_wave(alg))
-            stream = {"full": "streams[0]", "compute_only": "0", "launch": "stream"}[mode]
-            for line in body_pre(mode):
-                self.gen_add_code_line(line)
-            if mode == "full":
+            stream = {"full": "streams[0]", "single_timing": "streams[0]", "compute_only": "0", "launch": "stream"}[mode]
+            for line in body_pre("full" if single else mode):
+                self.gen_add_code_line(one(line))
+            if mode in ("full", "single_timing"):
                 self.gen_add_code_line("gpuErrchk(hipDeviceSynchronize());")
             self.gen_add_code_line("// then call the kernel")
+            if single:
+                self.gen_add_code_line("struct timespec start, end; clock_gettime(CLOCK_MONOTONIC,&start);")
             for line in launches:
+                line = line.replace("_kernel<T>@L", "_kernel_single_timing<T>@L") if single else line
                 self.gen_add_code_line(line.replace("@L", "<<<blocks,threads,lds_bytes,%s>>>" % stream))
             self.gen_add_code_line("gpuErrchk(hipGetLastError());")
             if mode != "launch":
                 self.gen_add_code_line("gpuErrchk(hipDeviceSynchronize());")
-            if mode == "full":
+            if single:
+                self.gen_add_code_line("clock_gettime(CLOCK_MONOTONIC,&end);")
+            if mode in ("full", "single_timing"):
                 for line in body_post:
-                    self.gen_add_code_line(line)
+                    self.gen_add_code_line(one(line))
+            if single:
+                self.gen_add_code_line("printf(\"Single Call %s %%fus\\n\",time_delta_us_timespec(start,end)/static_cast<double>(num_timesteps));" % timing_label)
             self.gen_add_end_function()
 
     def gen_launch_helpers(self):

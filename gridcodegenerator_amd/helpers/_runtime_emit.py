@@ -248,6 +248,12 @@ class RuntimeEmitMixin:
             "    T *p_;",
             "    __host__ __device__ __forceinline__ void put(int i, T v){p_[i] = v;}",
             "};",
+            "// sink of the *_kernel_single_timing latency twins: one lane of the grid writes the (single) result row",
+            "template <typename T>",
+            "struct grid_out_first {",
+            "    T *p_; bool on_;",
+            "    __host__ __device__ __forceinline__ void put(int i, T v){if (on_){p_[i] = v;}}",
+            "};",
             "",
             "// ---- wave-level staging: W lanes <-> W consecutive configurations (W = 64 for whole waves), no block barrier ----",
             "__device__ __forceinline__ void grid_wave_sync(){",

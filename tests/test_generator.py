@@ -109,3 +109,23 @@ def test_generation_is_deterministic(robots):
         finally:
             os.chdir(cwd)
     assert a.code_str == b.code_str
+
+
+def test_single_timing_twins_are_emitted(generated):
+    """Reference mode 1 (GRiDCodeGenerator.py:243-279: every algorithm is emitted with single_call_timing kernels and a
+    *_single_timing host wrapper that prints `Single Call <label>`): same names and argument lists here."""
+    for name in ("iiwa7",):
+        text = generated[1].code_str
+        for sig in ("void inverse_dynamics_kernel_single_timing(T *d_c, const T *d_q_qd, const int stride_q_qd, const T *d_qdd, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS)",
+                    "void inverse_dynamics_kernel_single_timing(T *d_c, const T *d_q_qd, const int stride_q_qd, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS)",
+                    "void direct_minv_kernel_single_timing(T *d_Minv, const T *d_q, const int stride_q, const robotModel<T> *d_robotModel, const int NUM_TIMESTEPS)",
+                    "void forward_dynamics_kernel_single_timing(T *d_qdd, const T *d_q_qd_u, const int stride_q_qd_u, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS)",
+                    "void inverse_dynamics_gradient_kernel_single_timing(T *d_dc_du, const T *d_q_qd, const int stride_q_qd, const T *d_qdd, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS)",
+                    "void inverse_dynamics_gradient_kernel_single_timing(T *d_dc_du, const T *d_q_qd, const int stride_q_qd, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS)",
+                    "void forward_dynamics_gradient_kernel_single_timing(T *d_df_du, const T *d_q_qd, const int stride_q_qd, const T *d_qdd, const T *d_Minv, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS)",
+                    "void forward_dynamics_gradient_kernel_single_timing(T *d_df_du, const T *d_q_qd_u, const int stride_q_qd_u, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS)"):
+            assert sig in text, (name, sig)
+        for host_name, label in (("inverse_dynamics", "ID"), ("direct_minv", "Minv"), ("forward_dynamics", "FD"),
+                                 ("inverse_dynamics_gradient", "ID_DU"), ("forward_dynamics_gradient", "FD_DU")):
+            assert "void %s_single_timing(gridData<T> *hd_data, const robotModel<T> *d_robotModel, " % host_name in text
+            assert 'printf("Single Call %s %%fus\\n",time_delta_us_timespec(start,end)/static_cast<double>(num_timesteps));' % label in text

@@ -11,6 +11,8 @@ kernels compute in fp32 and store fp32.  Norm-wise = max|err| / max|ref| over th
 (The generator can also emit fp64 arithmetic, precision="fp64"; that build is checked on the CPU in
 tests/test_host_compiled.py (2e-7) but is NOT shipped for the GPU this round: see DESIGN.md "fp64".)
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -350,3 +352,23 @@ def test_minv_times_mass_matrix_on_gpu(handles, torch_cuda):
         e = np.zeros((K, n), np.float32); e[:, i] = 1.0
         M[:, :, i] = h.inverse_dynamics(x, qdd=e, gravity=0.0)
     assert np.abs(np.einsum("kij,kjl->kil", Mi, M) - np.eye(n)).max() < 5e-4
+
+
+def test_single_timing_twins(torch_cuda, tmp_path):
+    """The *_single_timing host wrappers / *_kernel_single_timing kernels of the generated header (reference mode 1):
+    a GRiD-style main() compiled with hipcc against the iiwa-7 header must leave the same results in the host buffers
+    as the mode-0 wrappers and print the reference's `Single Call <label>` lines."""
+    import subprocess
+    from gridcodegenerator_amd import host
+    host.build_library("iiwa7", "fp32")
+    header = host.library_paths("iiwa7")["header"]
+    exe = str(tmp_path / "single_timing_harness")
+    here = os.path.dirname(os.path.abspath(__file__))
+    cmd = [host._hipcc(), "--offload-arch=gfx950", "-O1", "-ffp-contract=off", "-std=c++17",
+           "-DGRID_HEADER=\"%s\"" % header, "-DGRID_NS=grid_iiwa7", os.path.join(here, "single_timing_harness.hip"), "-o", exe]
+    subprocess.run(cmd, check=True, timeout=900)
+    run = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    out = run.stdout
+    assert run.returncode == 0 and "ALL MATCH" in out, out
+    for label in ("ID", "Minv", "FD", "ID_DU", "FD_DU"):
+        assert "Single Call %s " % label in out, out
