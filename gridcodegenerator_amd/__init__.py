@@ -4,3 +4,4 @@
 (reference ``__init__.py:1``).
 """
 from .GRiDCodeGenerator import GRiDCodeGenerator  # noqa: F401
+from .urdf import URDFParser, load_urdf, robot_to_urdf  # noqa: F401  (URDF -> robot object, the step before the generator)
