@@ -37,9 +37,10 @@ from .algorithms._emit import AlgorithmEmitMixin
 from .emit.model import RobotSpec
 from .helpers._runtime_emit import RuntimeEmitMixin
 from .helpers._text import TextMixin
+from .verification import VerificationMixin
 
 
-class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin):
+class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin, VerificationMixin):
     def __init__(self, robotObj, DEBUG_MODE=False, NEED_PRINT_MAT=False, USE_DYNAMIC_SHARED_MEM=True,
                  FILE_NAMESPACE="grid", *, precision="fp32", trig="fast", suggested_threads=64, max_threads=256,
                  out_chunk=64, emit_order="demand", emit_inner_api=True, suggested_max_blocks=2048, fence_every=0, grad_splits="auto", out_mode="staged", packed=False, waves_per_simd=1, pipeline="auto", grad_schedule="auto", grad_table=False):
