@@ -1,4 +1,4 @@
-"""Column-split kernels of one robot against the unsplit kernel and the oracle (small batch).  usage: check_splits.py robot"""
+"""Column-split kernels of one robot against the unsplit kernel and the oracle (small batch).  usage: python tests/gpu_checks/check_splits.py robot"""
 import sys; sys.path.insert(0, '.')
 import numpy as np, torch
 from gridcodegenerator_amd import host

@@ -1,5 +1,5 @@
 """Correctness + timing of every gradient kernel variant of one robot (single-kernel and two-pass), small and full batch.
-usage: check_atlas.py [robot] [Kbig]"""
+usage: python tests/gpu_checks/check_variants.py [robot] [Kbig]"""
 import sys, time; sys.path.insert(0, '.')
 import numpy as np
 t0 = time.time()
