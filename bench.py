@@ -56,8 +56,15 @@ def cpu_baseline(robot_name, q, qd, u, seconds):
         O.fd_grad(T, q64, qd64, u64)
         passes += 1
     dt = time.perf_counter() - t0
-    return dict(value=passes * q.shape[0] / dt, unit="evals/s", cores=1, kind="port",
-                sample="%d pass(es) of oracle.fd_grad (numpy float64, batch-vectorised) over the same %d-configuration batch, %.1f s"
+    cpu = "unknown CPU"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            cpu = next(line.split(":", 1)[1].strip() for line in fh if line.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
+    return dict(value=passes * q.shape[0] / dt, unit="evals/s", cores=1, kind="port", cpu=cpu,
+                host_cores_available=len(os.sched_getaffinity(0)),
+                sample="%d pass(es) of oracle.fd_grad (numpy float64, batch-vectorised, one process) over the same %d-configuration batch, %.1f s"
                        % (passes, q.shape[0], dt))
 
 
@@ -147,6 +154,8 @@ def main():
                        "outputs_finite": finite},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, profiles/)", "kernel": "forward_dynamics_gradient_kernel", "kernel_avg_us": 1e3 * kern_ms,
+                         "traffic_GBps": (traffic / (kern_ms * 1e-3) / 1e9) if traffic else None,
+                         "traffic_frac": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                          "algorithmic_bytes_per_eval": host.algorithmic_bytes(host.ALG_FD_DU, n),
                          "kernel_evals_per_s": K / (kern_ms * 1e-3)},
         }
