@@ -205,7 +205,7 @@ class Tracer:
         return self.fma(vx, vy, V(self, rc))
 
     # --- paired (2-wide) operations ------------------------------------------------------------------
-    use_packed = True
+    use_packed = False      # class-wide switch (GRiDCodeGenerator(packed=...) sets it for a build); off: what ships
 
     def _halves(self, x):
         if isinstance(x, P):

@@ -214,3 +214,21 @@ def test_recompute_cores_with_table_and_column_groups(robot_name, setup, variant
     gotc = _scatter(trc, _run(trc, inputs), 2 * n * len(cols))
     want = np.concatenate([ref[:, :, c] for c in cols] + [ref[:, :, n + c] for c in cols], axis=1)
     assert relerr(gotc, want)[0] < 1e-12
+
+
+def test_packed_pair_traces(setup):
+    """EXPERIMENTAL packed=True emission (the d/dq and d/dqd recursions as v_pk_fma_f32 pairs): same values, fewer
+    instructions.  Not shipped (hipcc allocates the 64-bit pairs badly) but kept correct."""
+    from gridcodegenerator_amd.emit.trace import Tracer
+    spec, T, q, qd, u = setup("iiwa7")
+    plain = cores.core_forward_dynamics_gradient(spec, False)
+    assert not any(k.startswith("pk") for k in plain.op_counts())
+    Tracer.use_packed = True
+    try:
+        packed = cores.core_forward_dynamics_gradient(spec, False)
+    finally:
+        Tracer.use_packed = False
+    assert packed.op_counts().get("pkfma", 0) > 1000 and packed.arith_instructions() < 0.8 * plain.arith_instructions()
+    ref = _grad_flat(O.fd_grad(T, q, qd, u), spec.n)
+    assert relerr(_run(packed, _inputs(spec.n, q, qd, u=u)), ref)[0] < 1e-12
+    assert relerr(_run(plain, _inputs(spec.n, q, qd, u=u)), ref)[0] < 1e-12
