@@ -43,7 +43,7 @@ from .verification import VerificationMixin
 class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin, VerificationMixin):
     def __init__(self, robotObj, DEBUG_MODE=False, NEED_PRINT_MAT=False, USE_DYNAMIC_SHARED_MEM=True,
                  FILE_NAMESPACE="grid", *, precision="fp32", trig="fast", suggested_threads=64, max_threads=256,
-                 out_chunk=64, emit_order="demand", emit_inner_api=True, suggested_max_blocks=2048, fence_every=0, grad_splits="auto", out_mode="staged", packed=False, waves_per_simd=1, pipeline="auto", grad_schedule="auto", grad_table=False):
+                 out_chunk=64, emit_order="demand", emit_inner_api=True, suggested_max_blocks=2048, fence_every=0, grad_splits="auto", out_mode="staged", packed=False, waves_per_simd=1, pipeline="auto", grad_schedule="auto", grad_table=False, split_fences=True):
         if precision not in ("fp32", "fp64"):
             raise ValueError("precision must be 'fp32' or 'fp64'")
         if trig not in ("fast", "libm", "f64"):
@@ -77,6 +77,7 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin, Verific
         assert grad_schedule in ("auto", "fused", "recompute")
         self.grad_schedule = ("recompute" if self.spec.n > 12 else "fused") if grad_schedule == "auto" else grad_schedule
         self.grad_table = bool(grad_table) and self.grad_schedule == "recompute"
+        self.split_fences = bool(split_fences)
         self.kernel_instances = []
         self.split_stats = {}
         self.emit_inner_api = bool(emit_inner_api)

@@ -130,7 +130,7 @@ class AlgorithmEmitMixin:
                  "GRID_MAX_THREADS threads is accepted (the dynamic LDS must cover ceil(threads/64) wave regions)"]
         if parts:
             notes += ["COLUMN-SPLIT variant for small batches: %d column groups %s; block b computes group b %% %d for tile group b / %d,"
-                      % (len(parts), [(c[0], c[-1]) for (_, c) in parts], len(parts), len(parts)),
+                      % (len(parts), [list(c) for (_, c) in parts], len(parts), len(parts)),
                       "every group repeats the shared prefix (X(q), Minv, RNEA) -- the SIMDs it uses would otherwise idle.",
                       "gridDim must be a multiple of %d (use the *_split_launch helper)" % len(parts)]
         self.gen_add_func_doc(doc, notes, params, None)
@@ -185,7 +185,12 @@ class AlgorithmEmitMixin:
                 ch = chunk or self._chunk_for(len0)
                 assert 64 * ch <= self.lds_per_wave(alg)
                 self.gen_add_code_line("case %d: {" % pi, True)
-                if direct:
+                contiguous = list(cols) == list(range(cols[0], cols[-1] + 1))
+                if not contiguous:
+                    assert not direct and 64 * n <= self.lds_per_wave(alg)
+                    self.gen_add_code_line("grid_out_cols<T,%d,%d,%s> out = {s_wave, d_%s, k0, it.lane, it.W, NUM_TIMESTEPS};   // columns %s"
+                                           % (n_out, n, ",".join(str(c) for c in cols), out_name, list(cols)))
+                elif direct:
                     self.gen_add_code_line("grid_out_direct<T,%d,%d,%d> out = {d_row};" % (n * cols[0], len0, n * n + n * cols[0]))
                 else:
                     self.gen_add_code_line("grid_out_staged<T,%d,%d,%d,%d,%d,%d> out = {s_wave, d_%s, k0, it.lane, it.W, NUM_TIMESTEPS};"
@@ -383,10 +388,19 @@ class AlgorithmEmitMixin:
         if not cand:
             return base, []
         cost = cores.range_cost_function(self.spec, builder, exact=(n <= 8))
+        use_sets = (n <= 8 and self.out_mode == "staged" and not getattr(builder, "recompute", False))
+        full = builder(None) if use_sets else None
         picked = []
         last = base
         for S in cand:
-            parts, est = cores.balanced_column_split(self.spec, S, cost)
+            if S > n:
+                continue
+            if use_sets and S >= 3:
+                # arbitrary column sets (exhaustive, exact: cores.optimal_column_sets) for the splits that serve small batches;
+                # the 2-way split serves full-chip batches, where contiguous columns give 3-4x longer store runs
+                parts, est = cores.optimal_column_sets(self.spec, S, full)
+            else:
+                parts, est = cores.balanced_column_split(self.spec, S, cost)
             if len(parts) != S or any(not c for c in parts):
                 continue
             if self.grad_splits != "auto" or n <= 8 or getattr(builder, "recompute", False) or est < 0.97 * last:
@@ -401,15 +415,16 @@ class AlgorithmEmitMixin:
     def _emit_split_family(self, alg, kernel_base, core_base, doc, out_name, primary, has_gravity, accessor, builder, launch_args):
         """Cores + kernels + a launcher for the column-split variants of a gradient kernel."""
         base, chosen = self._choose_splits(builder)
-        self.split_stats[alg] = dict(base_ops=base, splits={S: dict(parts=[(c[0], c[-1]) for c in parts], worst_ops=worst)
+        self.split_stats[alg] = dict(base_ops=base, splits={S: dict(parts=[list(c) for c in parts], worst_ops=worst)
                                                              for (S, parts, worst) in chosen})
         for (S, parts, worst) in chosen:
             named = []
             for pi, cols in enumerate(parts):
                 cname = "%s_s%dp%d" % (core_base, S, pi)
                 rec = getattr(builder, "recompute", False)
-                self._emit_core(cname, "%s: column group %d of %d (columns %d..%d of d/dq and of d/dqd)"
-                                % (doc, pi, S, cols[0], cols[-1]), builder(cols), order="creation" if rec else None)
+                self._emit_core(cname, "%s: column group %d of %d (columns %s of d/dq and of d/dqd)"
+                                % (doc, pi, S, list(cols)), builder(cols), order="creation" if rec else None,
+                                fence_stores=(self.split_fences or S < 3))
                 named.append((cname, cols))
             self._emit_kernel(alg, "%s_split%d" % (kernel_base, S), None, doc + " (column-split x%d)" % S, out_name,
                               primary, [], has_gravity, accessor, parts=named, chunk=self.spec.n if rec else None)

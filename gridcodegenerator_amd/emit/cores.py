@@ -100,8 +100,7 @@ def _out_grad(tr, spec, G, cols=None):
             for row in range(n):
                 tr.out(n * n + n * col + row, G[row][col].hi)
         return
-    assert list(cols) == list(range(cols[0], cols[-1] + 1))
-    i = 0
+    i = 0                                   # (cols need not be contiguous: the column-set sink maps every column back)
     for half in ("lo", "hi"):
         for col in cols:
             for row in range(n):
@@ -183,6 +182,80 @@ def balanced_column_split(spec, S, cost):
         bounds.append(e)
     bounds = bounds[::-1]
     return [list(range(bounds[i], bounds[i + 1])) for i in range(S)], best[S][n]
+
+def optimal_column_sets(spec, S, full):
+    """Best partition of the n gradient columns into S arbitrary SETS (n <= 8: exhaustive over all set partitions).
+    `full` is the trace of the whole gradient (outputs at n*col + row and n*n + n*col + row); the cost of a set is the number
+    of arithmetic nodes alive when only its columns are kept -- exactly what tracing that group would give, without
+    re-tracing.  Early columns are several times as expensive as late ones (d/dq_1 touches every descendant), so for a
+    7-joint chain {0,4}, {1}, {2,6}, {3,5} (2937 ops, = column 1 alone) beats the best contiguous split
+    {0,1}, {2}, {3}, {4,5,6} (3580).  Returns (parts sorted by first column, ops of the largest part)."""
+    n = spec.n
+    assert n <= 8 and 1 <= S <= n
+    roots = {c: [] for c in range(n)}
+    for (dst, ref) in full.outputs:
+        if not isinstance(dst, str) and not isinstance(ref, float):
+            roots[(int(dst) % (n * n)) // n].append(abs(ref))
+    arith = ("fma", "mul", "add", "pkfma", "pkmul", "pkadd")
+    memo = {}
+
+    def cost(mask):
+        if mask not in memo:
+            live = [False] * len(full.nodes)
+            stack = [r for c in range(n) if mask >> c & 1 for r in roots[c]]
+            while stack:
+                k = stack.pop()
+                if live[k]:
+                    continue
+                live[k] = True
+                stack.extend(d for d in full._deps(k) if not live[d])
+            memo[mask] = sum(1 for k in range(1, len(full.nodes)) if live[k] and full.nodes[k][0] in arith)
+        return memo[mask]
+
+    best = [None, None]
+
+    def rec(i, masks):
+        if i == n:
+            if len(masks) == S:
+                worst = max(cost(m) for m in masks)
+                if best[0] is None or worst < best[0]:
+                    best[0], best[1] = worst, list(masks)
+            return
+        if len(masks) + (n - i) < S:
+            return
+        for b in range(len(masks)):
+            masks[b] |= 1 << i
+            if best[0] is None or cost(masks[b]) < best[0]:       # the largest group can only grow
+                rec(i + 1, masks)
+            masks[b] &= ~(1 << i)
+        if len(masks) < S:
+            masks.append(1 << i)
+            rec(i + 1, masks)
+            masks.pop()
+
+    rec(0, [])
+    parts = sorted([[c for c in range(n) if m >> c & 1] for m in best[1]], key=lambda p: p[0])
+    return parts, best[0]
+
+
+def balanced_column_sets(spec, S, builder):
+    """Like balanced_column_split but the groups may be arbitrary column SETS: longest-processing-time assignment on the
+    single-column costs (shared prefix + marginal), then the exact cost of each group by tracing it.  Early columns are
+    several times as expensive as late ones (d/dq_1 touches every descendant), so {1}, {2,0}, {3,5}, {4,6} beats the best
+    contiguous split {0,1}, {2}, {3}, {4,5,6} of a 7-joint chain.  Returns (parts, ops of the largest part)."""
+    n = spec.n
+    single = [_arith_ops(builder([c])) for c in range(n)]
+    prefix = min(single)
+    bins = [[] for _ in range(S)]
+    load = [0.0] * S
+    for c in sorted(range(n), key=lambda c: -single[c]):
+        k = min(range(S), key=lambda k: (load[k], k))
+        bins[k].append(c)
+        load[k] += single[c] - prefix
+    parts = [sorted(b) for b in bins if b]
+    parts.sort(key=lambda p: p[0])
+    return parts, max(_arith_ops(builder(p)) for p in parts)
+
 
 # ------------------------------------------------------------------------------------------------
 # pointer-style ``_inner`` bodies (API parity with the reference's ALGORITHM_inner tier)
@@ -528,9 +601,7 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
 
     # cols = [c0..c1] (column-split kernels): only those columns, written at LOCAL indices -- d/dq columns at n*(col-c0),
     # d/dqd columns at n*len(cols) + n*(col-c0); the kernel sink maps the two runs back (see _out_grad)
-    if cols is not None:
-        assert list(cols) == list(range(cols[0], cols[-1] + 1))
-    lo_base = (lambda col: n * col) if cols is None else (lambda col: n * (col - cols[0]))
+    lo_base = (lambda col: n * col) if cols is None else (lambda col: n * list(cols).index(col))
     hi_off = n * n if cols is None else n * len(cols)
 
     def emit_column(col, dc):

@@ -403,6 +403,26 @@ class RuntimeEmitMixin:
             "    }",
             "};",
             "/**",
+            " * Staged sink of a column-split kernel whose block owns an arbitrary SET of gradient columns (COLS...): local values",
+            " * arrive column by column (N per column), first the d/dq columns of the set, then the d/dqd columns; chunk k is",
+            " * written to N*COLS[k] (k < number of columns) or N*N + N*COLS[k - number of columns].  Same flush as grid_out_staged.",
+            " */",
+            "template <typename T, int ROW, int N, int... COLS>",
+            "struct grid_out_cols {",
+            "    T *s_wave; T *d_dst; int k0; int lane; int W; int NUM_TIMESTEPS;",
+            "    __device__ __forceinline__ void put(const int i, const T v){",
+            "        constexpr int NC = sizeof...(COLS);",
+            "        constexpr int cols[NC] = {COLS...};",
+            "        s_wave[lane*N + (i % N)] = v;",
+            "        if (((i + 1) % N) == 0){",
+            "            const int chunk = i / N;",
+            "            const int base = (chunk < NC) ? N*cols[chunk] : N*N + N*cols[chunk - NC];",
+            "            grid_out_staged<T,ROW,N,N,0,N,0> run = {s_wave, d_dst, k0, lane, W, NUM_TIMESTEPS};",
+            "            run.template flush_len<N>(base);",
+            "        }",
+            "    }",
+            "};",
+            "/**",
             " * Direct output sink: each lane stores its own row (value i at immediate offset 4*i from the lane's row pointer).",
             " * One instruction per value and no LDS round trip; the W-way strided stores are merged by the L2.  Measured on",
             " * MI355X (tools/ubench/staging_floor.hip, 16384 x 98 floats): 5.8 us against 6.2-7.4 us for LDS-staged flat",

@@ -232,3 +232,23 @@ def test_packed_pair_traces(setup):
     ref = _grad_flat(O.fd_grad(T, q, qd, u), spec.n)
     assert relerr(_run(packed, _inputs(spec.n, q, qd, u=u)), ref)[0] < 1e-12
     assert relerr(_run(plain, _inputs(spec.n, q, qd, u=u)), ref)[0] < 1e-12
+
+
+def test_optimal_column_sets(setup):
+    """Exhaustive column-set partition: exact costs (equal to re-tracing the group), never worse than the best contiguous
+    split, every column exactly once."""
+    spec, T, q, qd, u = setup("iiwa7")
+    builder = lambda cols: cores.core_forward_dynamics_gradient(spec, False, cols)
+    full = builder(None)
+    contiguous_cost = cores.range_cost_function(spec, builder, exact=True)
+    for S in (3, 4):
+        parts, worst = cores.optimal_column_sets(spec, S, full)
+        assert sorted(c for p in parts for c in p) == list(range(spec.n)) and len(parts) == S
+        assert worst == max(cores._arith_ops(builder(p)) for p in parts)
+        assert worst <= cores.balanced_column_split(spec, S, contiguous_cost)[1]
+    # a non-contiguous group evaluates to the same numbers as the full gradient restricted to its columns
+    cols = [0, 4]
+    got = _scatter(builder(cols), _run(builder(cols), _inputs(spec.n, q, qd, u=u)), 2 * spec.n * len(cols))
+    ref = O.fd_grad(T, q, qd, u)
+    want = np.concatenate([ref[:, :, c] for c in cols] + [ref[:, :, spec.n + c] for c in cols], axis=1)
+    assert relerr(got, want)[0] < 1e-12
