@@ -27,6 +27,10 @@ Generation-time knobs that have no reference counterpart are keyword-only:
     grad_table       bool             recompute schedule only: park sin q, cos q, qd, qdd in a per-wave LDS table and re-load them per
                      column instead of keeping them in registers (Atlas-30: no scratch at all, but 16 % more instructions and
                      measured slower: 186 vs 163 us at K = 32768) -- off by default, exercised by the mixed5 test robot
+    split_sets       bool             column groups of the S >= 3 split kernels may be arbitrary column SETS (exact exhaustive
+                     partition, cores.optimal_column_sets: iiwa-7 dFD x4 worst group 3580 -> 2937 ops).  Measured: 9.4 vs 10.1 us at
+                     K=4096 but 12.05 vs 11.46 us at K=16384 (one flush per column instead of one per group half) -- off by default
+    split_fences     bool             scheduling fence after every output store also in the S >= 3 split kernels (without: 13.0 vs 12.0 us)
     waves_per_simd                    __launch_bounds__ occupancy hint for the unsplit kernels (caps registers at 512/w)
     grad_splits      "auto" | list    column-split variants of the two gradient kernels to emit (small-batch speed)
     fence_every                       extra scheduling fence every N emitted statements (0 = none).  A fence always
@@ -43,7 +47,7 @@ from .verification import VerificationMixin
 class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin, VerificationMixin):
     def __init__(self, robotObj, DEBUG_MODE=False, NEED_PRINT_MAT=False, USE_DYNAMIC_SHARED_MEM=True,
                  FILE_NAMESPACE="grid", *, precision="fp32", trig="fast", suggested_threads=64, max_threads=256,
-                 out_chunk=64, emit_order="demand", emit_inner_api=True, suggested_max_blocks=2048, fence_every=0, grad_splits="auto", out_mode="staged", packed=False, waves_per_simd=1, pipeline="auto", grad_schedule="auto", grad_table=False, split_fences=True):
+                 out_chunk=64, emit_order="demand", emit_inner_api=True, suggested_max_blocks=2048, fence_every=0, grad_splits="auto", out_mode="staged", packed=False, waves_per_simd=1, pipeline="auto", grad_schedule="auto", grad_table=False, split_fences=True, split_sets=False):
         if precision not in ("fp32", "fp64"):
             raise ValueError("precision must be 'fp32' or 'fp64'")
         if trig not in ("fast", "libm", "f64"):
@@ -78,6 +82,7 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin, Verific
         self.grad_schedule = ("recompute" if self.spec.n > 12 else "fused") if grad_schedule == "auto" else grad_schedule
         self.grad_table = bool(grad_table) and self.grad_schedule == "recompute"
         self.split_fences = bool(split_fences)
+        self.split_sets = bool(split_sets)
         self.kernel_instances = []
         self.split_stats = {}
         self.emit_inner_api = bool(emit_inner_api)

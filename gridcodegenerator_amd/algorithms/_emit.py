@@ -388,7 +388,7 @@ class AlgorithmEmitMixin:
         if not cand:
             return base, []
         cost = cores.range_cost_function(self.spec, builder, exact=(n <= 8))
-        use_sets = (n <= 8 and self.out_mode == "staged" and not getattr(builder, "recompute", False))
+        use_sets = (self.split_sets and n <= 8 and self.out_mode == "staged" and not getattr(builder, "recompute", False))
         full = builder(None) if use_sets else None
         picked = []
         last = base

@@ -97,7 +97,7 @@ def build_library(robot_name, precision="fp32", force=False, verbose=False, extr
 
 
 # generator options used when a built-in robot is built without explicit options (tests rely on these)
-DEFAULT_GEN_KWARGS = {"mixed5": {"pipeline": True, "grad_schedule": "recompute", "grad_table": True}}   # the small test robot exercises the two-pass kernels and the recomputing (LDS table) schedule, prismatic joints included
+DEFAULT_GEN_KWARGS = {"mixed5": {"pipeline": True, "grad_schedule": "recompute", "grad_table": True, "split_sets": True}}   # the small test robot exercises the two-pass kernels and the recomputing (LDS table) schedule, prismatic joints included
 
 
 def _build_library_locked(robot_name, precision, force, verbose, extra_flags, gen_kwargs):
