@@ -81,7 +81,13 @@ class AlgorithmEmitMixin:
     def _emit_core(self, name, doc, tracer, order=None, fence_stores=True, fence_stmt="GRID_SCHED_FENCE();"):
         """template <T, C, In, Out> void name(const In &in, Out &out, const T gravity)."""
         self.core_stats[name] = dict(tracer.op_counts(), flops=tracer.flops())
-        fence = " GRID_SCHED_FENCE();" if fence_stores else ""
+        stride = max(1, int(getattr(self, "fence_stride", 1)))
+        counter = [0]
+
+        def fence_after_store():
+            # a scheduling fence after every `fence_stride`-th output store (1 = after each: the measured optimum)
+            counter[0] += 1
+            return " GRID_SCHED_FENCE();" if (fence_stores and counter[0] % stride == 0) else ""
         self._emit_traced_function(
             doc, ["straight-line body for ONE configuration (one wavefront lane); compute type C, storage type T",
                   "in: accessor with q(i), qd(i), u(i), qdd(i), Minv(i); out: sink with put(i, value), i increasing"],
@@ -90,7 +96,7 @@ class AlgorithmEmitMixin:
             "__host__ __device__ __forceinline__",
             "void %s(const In &in, Out &out, const T gravity)" % name, tracer,
             store=lambda dst, val: ("in.tab_put(%s, (T)(%s));" % (dst[4:], val)) if isinstance(dst, str) and dst.startswith("tab:")
-            else "out.put(%s, (T)(%s));%s" % (dst, val, fence), order=order, fence_stmt=fence_stmt)
+            else "out.put(%s, (T)(%s));%s" % (dst, val, fence_after_store()), order=order, fence_stmt=fence_stmt)
 
     def _emit_load(self, dst, src, total, stride, piece=MAX_IN_PIECE):
         off = 0

@@ -284,12 +284,29 @@ class Tracer:
             return V(self, self._node(("fma", x, y, rc)))
         return V(self, -self._node(("fma", x, y, -rc)))
 
+    dot_ways = 1            # class-wide: > 1 splits long dot products over that many independent accumulators
+
     def dot(self, pairs, init=None):
-        """sum_i a_i*b_i (+ init) as an fma chain; zero terms vanish."""
-        acc = init if init is not None else V(self, 0.0)
+        """sum_i a_i*b_i (+ init) as an fma chain; zero terms vanish.  With dot_ways = w > 1 a product of >= 2w non-zero
+        terms is accumulated in w interleaved chains that are added at the end (shorter dependency chain, one more add per
+        extra chain, different rounding)."""
+        lifted = []
         for (a, b) in pairs:
             a = a if isinstance(a, (V, P)) else V(self, float(a))
             b = b if isinstance(b, (V, P)) else V(self, float(b))
+            if not (a.is_zero() or b.is_zero()):
+                lifted.append((a, b))
+        w = self.dot_ways
+        if w > 1 and len(lifted) >= 2 * w:
+            accs = [init if (init is not None and k == 0) else V(self, 0.0) for k in range(w)]
+            for i, (a, b) in enumerate(lifted):
+                accs[i % w] = self.fma(a, b, accs[i % w])
+            acc = accs[0]
+            for k in range(1, w):
+                acc = acc + accs[k]
+            return acc
+        acc = init if init is not None else V(self, 0.0)
+        for (a, b) in lifted:
             acc = self.fma(a, b, acc)
         return acc
 
