@@ -93,8 +93,13 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # rehearsal on a box with fewer GPUs than ranks (GRID_BENCH_REHEARSAL=1): every rank uses device 0 and the barrier /
+    # max-reduction run over gloo -- exercises the multi-process path (build lock, per-rank handles, aggregation) only
+    rehearsal = os.environ.get("GRID_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    dist = sharding.init_distributed("nccl")
+    dist = sharding.init_distributed("gloo" if rehearsal else "nccl")
 
     host.build_library(args.robot, args.precision)
     h = host.GridHandle(args.robot, device=local_rank, precision=args.precision)
@@ -120,7 +125,7 @@ def main():
             step()
         torch.cuda.synchronize()
 
-    elapsed = sharding.timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, dist, reduce_device="cuda")
+    elapsed = sharding.timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, dist, reduce_device="cpu" if rehearsal else "cuda")
 
     # in-stream kernel duration (HIP events recorded on the launch stream by the C ABI)
     kern_ms = h.time_device(host.ALG_FD_DU, d_out.data_ptr(), d_in.data_ptr(), 3 * n, K, gravity=GRAVITY,

@@ -372,3 +372,24 @@ def test_single_timing_twins(torch_cuda, tmp_path):
     assert run.returncode == 0 and "ALL MATCH" in out, out
     for label in ("ID", "Minv", "FD", "ID_DU", "FD_DU"):
         assert "Single Call %s " % label in out, out
+
+
+def test_bench_two_rank_rehearsal(torch_cuda):
+    """bench.py through torch.distributed.run with two ranks (rehearsal mode: both on device 0, gloo for the barrier and
+    the max-reduction): the multi-process path -- build lock, one handle per rank, whole-job aggregation -- produces one
+    JSON line with n_gpus = 2 and a global batch of 2 x 16384."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GRID_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3",
+           "--prewarm-s", "0.05", "--no-cpu-baseline"]
+    run = subprocess.run(cmd, cwd=repo, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, run.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 * 16384 and d["scaling"] == "weak"
+    assert d["value"] == pytest.approx(2 * 16384 * 1e3 / d["ms_per_step"], rel=1e-6) and d["config"]["outputs_finite"]
