@@ -407,6 +407,8 @@ class AlgorithmEmitMixin:
                 parts, est = cores.optimal_column_sets(self.spec, S, full)
             else:
                 parts, est = cores.balanced_column_split(self.spec, S, cost)
+                if getattr(builder, "recompute", False) and n > 12 and len(parts) == S:
+                    parts, est = cores.refine_contiguous_split(parts, builder)      # exact costs (the model is poor here)
             if len(parts) != S or any(not c for c in parts):
                 continue
             if self.grad_splits != "auto" or n <= 8 or getattr(builder, "recompute", False) or est < 0.97 * last:

@@ -183,6 +183,41 @@ def balanced_column_split(spec, S, cost):
     bounds = bounds[::-1]
     return [list(range(bounds[i], bounds[i + 1])) for i in range(S)], best[S][n]
 
+def refine_contiguous_split(parts, builder, max_steps=8):
+    """Hill-climb a contiguous column split on EXACT group costs (each evaluation traces a group): move one boundary column
+    out of the most expensive group into its neighbour while that lowers the maximum.  Used where the prefix + marginal
+    model of range_cost_function is poor (large robots, dFD: the Minv rows a group needs depend on its columns; Atlas-30
+    x4: 25.5 k -> about 21 k operations in the largest group).  Returns (parts, exact ops of the largest group)."""
+    parts = [list(p) for p in parts]
+    memo = {}
+
+    def cost(p):
+        key = (p[0], p[-1])
+        if key not in memo:
+            memo[key] = _arith_ops(builder(list(p)))
+        return memo[key]
+
+    for _ in range(max_steps):
+        costs = [cost(p) for p in parts]
+        worst = max(range(len(parts)), key=lambda i: costs[i])
+        best = None
+        for nb, col_from_end in ((worst - 1, False), (worst + 1, True)):
+            if nb < 0 or nb >= len(parts) or len(parts[worst]) < 2:
+                continue
+            if col_from_end:       # give the last column to the right neighbour
+                a, b = parts[worst][:-1], [parts[worst][-1]] + parts[nb]
+            else:                  # give the first column to the left neighbour
+                a, b = parts[worst][1:], parts[nb] + [parts[worst][0]]
+            new_max = max([cost(a), cost(b)] + [costs[i] for i in range(len(parts)) if i not in (worst, nb)])
+            if new_max < costs[worst] and (best is None or new_max < best[0]):
+                best = (new_max, nb, a, b)
+        if best is None:
+            break
+        _, nb, a, b = best
+        parts[worst], parts[nb] = a, b
+    return parts, max(cost(p) for p in parts)
+
+
 def optimal_column_sets(spec, S, full):
     """Best partition of the n gradient columns into S arbitrary SETS (n <= 8: exhaustive over all set partitions).
     `full` is the trace of the whole gradient (outputs at n*col + row and n*n + n*col + row); the cost of a set is the number
