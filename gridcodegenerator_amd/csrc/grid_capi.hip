@@ -217,11 +217,16 @@ static int effective_split(const grid_handle *h, int alg, int K) {
     if (want > 1) { for (int i = 0; i < n; i++) if (list[i] == want) return want; return 1; }
     const int tiles = (K + G::GRID_WAVE_SIZE - 1) / G::GRID_WAVE_SIZE;
     int best = 1;
-    // large robots: same rule (their column groups are not register-capped: one wave per SIMD); there is no 2-way fallback for
-    // full-chip batches because nothing can share a SIMD with a 512-register wave.  Atlas-30, K=16384: dID 160 -> 76 us,
-    // dFD 261 -> 185 us (S=4); K=32768 (S=2): dID 186 -> 110 us but dFD 320 -> 353 us (every group repeats Minv and the
-    // 236 MB output stream is already the larger cost), so dFD only splits up to one tile per CU
-    if (G::NUM_JOINTS > 12 && alg == GRID_ALG_FD_DU && tiles > GRID_CUS) return 1;
+    // Large robots (column groups of the recomputing schedule, not register-capped, no repeated prefix for dID): measured on
+    // Atlas-30 (tools/split_sweep.py, profiles/r01/sweep_atlas30_split_recompute.txt) the finest split wins for dID at EVERY
+    // batch (K=16384: 160 -> 76 us, 65536: 392 -> 325, 262144: 1367 -> 1252: shorter waves overlap their output stores with
+    // other waves' arithmetic), and for dFD (every group repeats Minv) up to 768 tiles (K=16384: 261 -> 125 us,
+    // 32768: 373 -> 253, 49152: 476 -> 421; 65536: 528 -> 543, so not beyond).
+    if (G::NUM_JOINTS > 12) {
+        if (alg == GRID_ALG_FD_DU && tiles > 3 * GRID_CUS) return 1;
+        for (int i = 0; i < n; i++) if (list[i] > best) best = list[i];
+        return best;
+    }
     for (int i = 0; i < n; i++) if ((long long)tiles * list[i] <= 4LL * GRID_CUS && list[i] > best) best = list[i];
     if (best == 1 && G::NUM_JOINTS <= 12) { for (int i = 0; i < n; i++) if (list[i] == 2) best = 2; }
     return best;

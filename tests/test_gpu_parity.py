@@ -156,8 +156,8 @@ def test_column_split_kernels_bitwise(handles, torch_cuda):
     torch = torch_cuda
     def expected_split(n, splits, K, alg):       # the C ABI's automatic choice (csrc/grid_capi.hip: effective_split)
         tiles = (K + 63) // 64
-        if n > 12 and alg == host.ALG_FD_DU and tiles > 256:
-            return 1
+        if n > 12:      # large robots: finest split always (dID) / up to 768 tiles (dFD)
+            return 1 if (alg == host.ALG_FD_DU and tiles > 768) else max(splits)
         best = max([S for S in splits if tiles * S <= 1024] or [1])
         return 2 if (best == 1 and n <= 12 and 2 in splits) else best
 
