@@ -337,6 +337,36 @@ def test_full_size_atlas30_65536(handles, tables, torch_cuda):
     _full_size_properties(handles("atlas30"), tables("atlas30"), 65536, 4, torch_cuda, check_rows=64)
 
 
+def test_full_size_atlas30_16384_column_groups(handles, tables, torch_cuda):
+    """north_star target "Atlas-30 at batch 16k": served by the x4 column-group kernels (one wave per SIMD)."""
+    from gridcodegenerator_amd import host
+    h = handles("atlas30")
+    assert h.get_split(host.ALG_FD_DU, 16384) == 4
+    _full_size_properties(h, tables("atlas30"), 16384, 6, torch_cuda, check_rows=64)
+
+
+def test_shard_size_atlas30_131072(handles, tables, torch_cuda):
+    """BASELINE.json configs[4]: one GPU's shard (131072 configurations, 944 MB of df_du) of the 1,048,576 batch."""
+    _full_size_properties(handles("atlas30"), tables("atlas30"), 131072, 5, torch_cuda, check_rows=32)
+
+
+def test_full_size_iiwa7_1024_inverse_dynamics(handles, tables, torch_cuda):
+    """BASELINE.json configs[1]: iiwa-7 RNEA + its gradient, fp32, batch 1024 -- every row against the oracle."""
+    torch = torch_cuda
+    h = handles("iiwa7")
+    n, K = h.n, 1024
+    q, qd, u = make_inputs(n, K, 2)
+    ref = oracle_all(tables("iiwa7"), q, qd, u)
+    d_in = torch.from_numpy(pack(q, qd, u)).cuda()
+    d_c = torch.empty((K, n), dtype=torch.float32, device="cuda")
+    d_dc = torch.empty((K, 2 * n * n), dtype=torch.float32, device="cuda")
+    h.inverse_dynamics_device(d_c.data_ptr(), d_in.data_ptr(), 3 * n, K)
+    h.inverse_dynamics_gradient_device(d_dc.data_ptr(), d_in.data_ptr(), 3 * n, K)
+    h.synchronize()
+    assert relerr(d_c.cpu().numpy(), ref["c"])[0] < TOL32["c"]
+    assert relerr(d_dc.cpu().numpy(), ref["dc_du_noqdd"])[0] < TOL32["dc_du"]
+
+
 def test_minv_times_mass_matrix_on_gpu(handles, torch_cuda):
     """M assembled column-wise from the GPU RNEA (gravity 0, qd 0, qdd = e_i) times the GPU Minv = I."""
     torch = torch_cuda
