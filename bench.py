@@ -42,30 +42,55 @@ def make_inputs(n, K, seed):
     return q, qd, u
 
 
-def cpu_baseline(robot_name, q, qd, u, seconds):
-    """numpy float64 oracle on the host cores (single process => cores = 1): whole passes over the same batch until about
-    `seconds` of CPU work have been done (at least one pass)."""
+def _cpu_worker(job):
+    """One process of the CPU baseline: whole passes of the numpy oracle over its slice for about `seconds`."""
+    robot_name, q64, qd64, u64, seconds = job
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=1)      # one BLAS/OpenMP thread per worker process
+    except Exception:                              # pragma: no cover
+        limiter = None
     from gridcodegenerator_amd.robots import get_robot
     from oracle import rbd_oracle as O
     T = O.RobotTables(get_robot(robot_name))
-    q64, qd64, u64 = (a.astype(np.float64) for a in (q, qd, u))
-    O.fd_grad(T, q64[:64], qd64[:64], u64[:64])  # warm numpy
+    O.fd_grad(T, q64[:8], qd64[:8], u64[:8])
     passes = 0
     t0 = time.perf_counter()
     while passes == 0 or time.perf_counter() - t0 < seconds:
         O.fd_grad(T, q64, qd64, u64)
         passes += 1
     dt = time.perf_counter() - t0
+    del limiter
+    return passes * q64.shape[0], dt
+
+
+def cpu_baseline(robot_name, q, qd, u, seconds, cores):
+    """numpy float64 oracle on `cores` host cores: the batch is cut into `cores` contiguous slices, one forked worker process
+    each (forked BEFORE anything touches the GPU), every worker repeats whole passes over its slice for about `seconds`.
+    value = all evaluations done / the longest worker time.  cores = 1 runs in this process."""
+    q64, qd64, u64 = (a.astype(np.float64) for a in (q, qd, u))
+    K = q.shape[0]
+    cores = max(1, min(int(cores), K))
+    bounds = [(i * K) // cores for i in range(cores + 1)]
+    jobs = [(robot_name, q64[a:b], qd64[a:b], u64[a:b], seconds) for a, b in zip(bounds[:-1], bounds[1:])]
+    if cores == 1:
+        results = [_cpu_worker(jobs[0])]
+    else:
+        import multiprocessing
+        with multiprocessing.get_context("fork").Pool(cores) as pool:
+            results = pool.map(_cpu_worker, jobs)
+    evals = sum(r[0] for r in results)
+    dt = max(r[1] for r in results)
     cpu = "unknown CPU"
     try:
         with open("/proc/cpuinfo") as fh:
             cpu = next(line.split(":", 1)[1].strip() for line in fh if line.startswith("model name"))
     except (OSError, StopIteration):
         pass
-    return dict(value=passes * q.shape[0] / dt, unit="evals/s", cores=1, kind="port", cpu=cpu,
+    return dict(value=evals / dt, unit="evals/s", cores=cores, kind="port", cpu=cpu,
                 host_cores_available=len(os.sched_getaffinity(0)),
-                sample="%d pass(es) of oracle.fd_grad (numpy float64, batch-vectorised, one process) over the same %d-configuration batch, %.1f s"
-                       % (passes, q.shape[0], dt))
+                sample="oracle.fd_grad (numpy float64, batch-vectorised) over the same %d-configuration batch cut into %d slices, "
+                       "one process per slice, whole passes for %.1f s: %d evaluations" % (K, cores, dt, evals))
 
 
 def main():
@@ -77,7 +102,8 @@ def main():
     ap.add_argument("--batch", type=int, default=16384, help="configurations per GPU")
     ap.add_argument("--precision", default="fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work of the cpu_baseline sample (whole passes)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall seconds of the cpu_baseline sample (whole passes)")
+    ap.add_argument("--cpu-cores", type=int, default=0, help="worker processes of the cpu_baseline (0 = all cores of this process, at most 16)")
     ap.add_argument("--prewarm-s", type=float, default=0.3, help="seconds of untimed launches before the warm-up (clock ramp)")
     ap.add_argument("--blocks", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
@@ -85,10 +111,19 @@ def main():
     ap.add_argument("--all-kernels", action="store_true", help="also time the other four kernels (reported under 'kernels')")
     args = ap.parse_args()
 
-    import torch
     from gridcodegenerator_amd import host, sharding
+    from gridcodegenerator_amd.robots import get_robot
 
     rank, local_rank, world = sharding.env_rank()
+    # CPU baseline first: its worker processes are forked before this process initialises the GPU runtime
+    cpu_line = None
+    if world == 1 and not args.no_cpu_baseline:
+        n0 = get_robot(args.robot).get_num_joints()
+        q0, qd0, u0 = make_inputs(n0, args.batch, 3 + rank)
+        cores = args.cpu_cores if args.cpu_cores > 0 else min(16, len(os.sched_getaffinity(0)))
+        cpu_line = cpu_baseline(args.robot, q0, qd0, u0, args.cpu_seconds, cores)
+
+    import torch
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
@@ -173,8 +208,8 @@ def main():
                 by = host.algorithmic_bytes(a, n) * K
                 kern[host.ALG_NAMES[a]] = {"avg_us": 1e3 * ms, "evals_per_s": K / (ms * 1e-3), "alg_GBps": by / (ms * 1e-3) / 1e9}
             out["kernels"] = kern
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.robot, q, qd, u, args.cpu_seconds)
+        if cpu_line is not None:
+            out["cpu_baseline"] = cpu_line
         print(json.dumps(out), flush=True)
     h.close()
     if dist is not None:
