@@ -15,7 +15,7 @@ Sharding: the batch dimension is embarrassingly parallel, every rank owns its ow
 roofline: algorithmic bytes per launch = 4*(3n + 2n^2) * batch, divided by the
 kernel's average launch duration measured with HIP events on the launch stream (grid_time_device).
 cpu_baseline: the numpy oracle (oracle/rbd_oracle.py, a float64 port of the reference algorithm) timed on
-this box's host cores, rank 0 at N=1 only, on a bounded sample.
+this box's host cores (up to 16 worker processes, count reported), rank 0 at N=1 only, on a bounded sample.
 """
 import argparse
 import json
