@@ -47,7 +47,7 @@ from .verification import VerificationMixin
 class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin, VerificationMixin):
     def __init__(self, robotObj, DEBUG_MODE=False, NEED_PRINT_MAT=False, USE_DYNAMIC_SHARED_MEM=True,
                  FILE_NAMESPACE="grid", *, precision="fp32", trig="fast", suggested_threads=64, max_threads=256,
-                 out_chunk=64, emit_order="demand", emit_inner_api=True, suggested_max_blocks=2048, fence_every=0, grad_splits="auto", out_mode="staged", packed=False, waves_per_simd=1, pipeline="auto", grad_schedule="auto", grad_table=False, split_fences=True, split_sets=False, fence_stride=1, dot_ways=1):
+                 out_chunk=64, emit_order="demand", emit_inner_api=True, suggested_max_blocks=2048, fence_every=0, grad_splits="auto", out_mode="staged", packed=False, waves_per_simd=1, pipeline="auto", grad_schedule="auto", grad_table=False, split_fences=True, split_sets=False, fence_stride=1, dot_ways=1, split_cap=(2,)):
         if precision not in ("fp32", "fp64"):
             raise ValueError("precision must be 'fp32' or 'fp64'")
         if trig not in ("fast", "libm", "f64"):
@@ -85,6 +85,7 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin, Verific
         self.split_sets = bool(split_sets)
         self.fence_stride = int(fence_stride)
         self.dot_ways = int(dot_ways)
+        self.split_cap = tuple(int(x) for x in split_cap)
         self.kernel_instances = []
         self.split_stats = {}
         self.emit_inner_api = bool(emit_inner_api)

@@ -143,7 +143,7 @@ class AlgorithmEmitMixin:
         self.gen_add_code_line("template <typename T, typename C = typename grid_compute<T>::type>")
         # the 2-way split is the one used when the batch fills the chip: cap it at 256 registers so two waves share a SIMD
         # (2nd argument = waves per SIMD).  Finer splits only run when there are fewer waves than SIMDs: no cap, no spills.
-        occ = 2 if (parts and len(parts) == 2 and n <= 12) else self.waves_per_simd
+        occ = 2 if (parts and len(parts) in getattr(self, "split_cap", (2,)) and n <= 12) else self.waves_per_simd
         self.gen_add_code_line("__global__ __launch_bounds__(GRID_MAX_THREADS%s)" % (", %d" % occ if occ > 1 else ""))
         self.gen_add_code_line(sig + " {", True)
         self.gen_add_code_lines([
