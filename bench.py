@@ -8,16 +8,24 @@ already resident in HBM -- launched through the C ABI on torch's current stream.
 steps, then exactly K steps bracketed by barrier + torch.cuda.synchronize(); the time is the MAX over
 ranks; rank 0 prints ONE JSON line.
 
+The line's top-level fields are the headline workload (BASELINE.json: iiwa-7, batch 16384 per GPU).  north_star's target
+also names Atlas-30, so the same run times it too, with the same bracket, and reports it under ``"secondary"``:
+Atlas-30 batch 16384 per GPU always, and for N > 1 additionally BASELINE config 5's shard (Atlas-30, 131072 per GPU).
+
 Sharding: the batch dimension is embarrassingly parallel, every rank owns its own contiguous slice
-(weak scaling: 16384 configurations per GPU), there is NO collective on the data path; torch.distributed
-(RCCL) is used only for the barrier and the max-over-ranks of the elapsed time.
+(weak scaling), there is NO collective on the data path; torch.distributed (RCCL) is used only for the
+barrier and the max-over-ranks of the elapsed time.
 
 roofline: algorithmic bytes per launch = 4*(3n + 2n^2) * batch, divided by the
-kernel's average launch duration measured with HIP events on the launch stream (grid_time_device).
+kernel's average launch duration measured with HIP events on the launch stream (grid_time_device).  ``kernel`` is the
+kernel the C ABI actually dispatched (e.g. ``..._kernel_split4``) with that kernel's registers.  ``traffic`` comes from
+the committed rocprofv3 PMC passes (profiles/pmc_traffic.json) and is printed only when that entry was measured on the
+same generated header (sha recorded with the entry) -- otherwise null.
 cpu_baseline: the numpy oracle (oracle/rbd_oracle.py, a float64 port of the reference algorithm) timed on
-this box's host cores (up to 16 worker processes, count reported), rank 0 at N=1 only, on a bounded sample.
+this box's host cores (count reported, see host_cores()), rank 0 at N=1 only, on a bounded sample.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -31,6 +39,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 GRAVITY = 9.81
+HEADLINE_METRIC = "FD-gradient evals/sec (iiwa-7, batch=16k) + achieved HBM GB/s vs peak"
 
 
 def make_inputs(n, K, seed):
@@ -40,6 +49,21 @@ def make_inputs(n, K, seed):
     qd = rng.uniform(-1.0, 1.0, (K, n)).astype(np.float32)
     u = rng.uniform(-1.0, 1.0, (K, n)).astype(np.float32)
     return q, qd, u
+
+
+def host_cores():
+    """Cores this process may really use: the scheduler affinity mask, cut down to the cgroup CPU quota when the container
+    has one (a one-GPU box exposes all 256 hardware threads in the mask but grants a share of them)."""
+    affinity = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, period = fh.read().split()
+            if q != "max":
+                quota = max(1, int(int(q) / int(period)))
+    except (OSError, ValueError):
+        pass
+    return (min(affinity, quota) if quota else affinity), affinity, quota
 
 
 def _cpu_worker(job):
@@ -70,7 +94,7 @@ def cpu_baseline(robot_name, q, qd, u, seconds, cores):
     value = all evaluations done / the longest worker time.  cores = 1 runs in this process."""
     q64, qd64, u64 = (a.astype(np.float64) for a in (q, qd, u))
     K = q.shape[0]
-    cores = max(1, min(int(cores), K))
+    cores = max(1, min(int(cores), K // 8))
     bounds = [(i * K) // cores for i in range(cores + 1)]
     jobs = [(robot_name, q64[a:b], qd64[a:b], u64[a:b], seconds) for a, b in zip(bounds[:-1], bounds[1:])]
     if cores == 1:
@@ -87,32 +111,140 @@ def cpu_baseline(robot_name, q, qd, u, seconds, cores):
             cpu = next(line.split(":", 1)[1].strip() for line in fh if line.startswith("model name"))
     except (OSError, StopIteration):
         pass
+    usable, affinity, quota = host_cores()
     return dict(value=evals / dt, unit="evals/s", cores=cores, kind="port", cpu=cpu,
-                host_cores_available=len(os.sched_getaffinity(0)),
+                host_cores_usable=usable, host_cores_affinity=affinity, cgroup_cpu_quota=quota,
                 sample="oracle.fd_grad (numpy float64, batch-vectorised) over the same %d-configuration batch cut into %d slices, "
                        "one process per slice, whole passes for %.1f s: %d evaluations" % (K, cores, dt, evals))
 
 
+def header_sha(robot, precision):
+    from gridcodegenerator_amd import host
+    try:
+        with open(host.library_paths(robot, precision)["header"], "rb") as fh:
+            return hashlib.sha256(fh.read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def committed_traffic(robot, K, kernel, sha):
+    """HBM bytes per launch of `kernel` from the committed PMC passes -- only if they were taken on this very header."""
+    try:
+        with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as fh:
+            e = json.load(fh).get("%s:%d:%s" % (robot, K, kernel))
+    except (OSError, ValueError):
+        return None, None
+    if not e or e.get("header_sha") != sha:
+        return None, None
+    return e.get("bytes"), e.get("round")
+
+
+class Workload:
+    """One robot / batch on this rank's GPU: device-resident inputs and outputs, one handle, the launch closure."""
+
+    def __init__(self, torch, host, robot, K, precision, device, seed, blocks=0, threads=0, split=0, coop=0):
+        host.build_library(robot, precision)
+        self.host, self.torch, self.robot, self.K, self.precision = host, torch, robot, K, precision
+        self.h = host.GridHandle(robot, device=device, precision=precision)
+        self.n = n = self.h.n
+        q, qd, u = make_inputs(n, K, seed)
+        self.d_in = torch.from_numpy(np.ascontiguousarray(np.concatenate([q, qd, u], axis=1))).cuda()
+        self.d_out = torch.empty((K, 2 * n * n), dtype=torch.float32, device="cuda")
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.blocks, self.threads = blocks, threads
+        self.h.set_split(host.ALG_FD_DU, split)
+        if coop:
+            self.h.set_coop(host.ALG_FD_DU, coop)
+        self.coop_used = self.h.get_coop(host.ALG_FD_DU, K)          # the tile-cooperative kernel takes precedence over a split
+        self.split_used = 1 if self.coop_used else self.h.get_split(host.ALG_FD_DU, K)
+
+    def step(self):
+        self.h.forward_dynamics_gradient_device(self.d_out.data_ptr(), self.d_in.data_ptr(), 3 * self.n, self.K, gravity=GRAVITY,
+                                                blocks=self.blocks, threads=self.threads, stream=self.stream)
+
+    def prewarm(self, seconds):
+        # Bring the GPU out of its idle power state (the default run is only a few ms of kernels).  Not warm-up, not steps.
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(50 if self.K <= 65536 else 5):
+                self.step()
+            self.torch.cuda.synchronize()
+
+    def measure(self, sharding, dist, steps, warmup, world, reduce_device):
+        host, torch = self.host, self.torch
+        elapsed = sharding.timed_steps(self.step, steps, warmup, torch.cuda.synchronize, dist, reduce_device=reduce_device)
+        reps = max(20, min(steps, 200)) if self.K <= 65536 else max(5, min(steps, 20))
+        kern_ms = self.h.time_device(host.ALG_FD_DU, self.d_out.data_ptr(), self.d_in.data_ptr(), 3 * self.n, self.K, gravity=GRAVITY,
+                                     blocks=self.blocks, threads=self.threads, stream=self.stream, reps=reps)
+        finite = bool(torch.isfinite(self.d_out).all().item())
+        n, K = self.n, self.K
+        kernel = "forward_dynamics_gradient_kernel" + ("_coop" if self.coop_used else ("_split%d" % self.split_used if self.split_used > 1 else ""))
+        attrs = self.h.L.kernel_attributes(host.ALG_FD_DU, split=self.split_used, coop=self.coop_used)
+        sha = header_sha(self.robot, self.precision)
+        traffic, traffic_round = committed_traffic(self.robot, K, kernel, sha)
+        alg_bytes = host.algorithmic_bytes(host.ALG_FD_DU, n) * K
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        return {
+            "value": sharding.aggregate_throughput(K, world, steps, elapsed), "unit": "evals/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": 1e3 * elapsed / steps, "dtype": self.h.L.compute_dtype,
+            "config": {"workload": "%s forward_dynamics_gradient_kernel, batch %d per GPU, fp32 I/O, device-resident (reference _compute_only)"
+                                   % (self.robot, K),
+                       "robot": self.robot, "num_joints": n, "batch_per_gpu": K, "global_batch": K * world,
+                       "parallelism": "batch-sharded x%d, independent streams, no collective on the data path" % world,
+                       "launch": {"blocks": self.blocks or "suggested", "threads": self.threads or self.h.L.constants["SUGGESTED_THREADS"],
+                                  "column_split": self.split_used, "tile_cooperative": bool(self.coop_used)},
+                       "kernel": {"name": kernel, "vgprs": attrs["numRegs"], "scratch_bytes_per_lane": attrs["scratch_bytes_per_lane"],
+                                  "header_sha": sha},
+                       "outputs_finite": finite},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": traffic,
+                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE passes of %s on this header; null = not measured on this header)"
+                                         % (traffic_round or "profiles/"),
+                         "kernel": kernel, "kernel_avg_us": 1e3 * kern_ms,
+                         "traffic_GBps": (traffic / (kern_ms * 1e-3) / 1e9) if traffic else None,
+                         "traffic_frac": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                         "algorithmic_bytes_per_eval": host.algorithmic_bytes(host.ALG_FD_DU, n),
+                         "kernel_evals_per_s": K / (kern_ms * 1e-3)},
+        }
+
+    def all_kernels(self):
+        host, torch, n, K = self.host, self.torch, self.n, self.K
+        kern = {}
+        bufs = {a: torch.empty((K, host.output_size(a, n)), dtype=torch.float32, device="cuda") for a in range(5)}
+        for a in range(5):
+            self.h.time_device(a, bufs[a].data_ptr(), self.d_in.data_ptr(), 3 * n, K, gravity=GRAVITY, stream=self.stream, reps=200)   # ramp
+            ms = self.h.time_device(a, bufs[a].data_ptr(), self.d_in.data_ptr(), 3 * n, K, gravity=GRAVITY, stream=self.stream, reps=200)
+            by = host.algorithmic_bytes(a, n) * K
+            kern[host.ALG_NAMES[a]] = {"avg_us": 1e3 * ms, "evals_per_s": K / (ms * 1e-3), "alg_GBps": by / (ms * 1e-3) / 1e9}
+        return kern
+
+    def close(self):
+        self.h.close()
+        del self.d_in, self.d_out
+
+
 def main():
+    from gridcodegenerator_amd import host, sharding
+    from gridcodegenerator_amd.robots import get_robot
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--robot", default="iiwa7")
     ap.add_argument("--batch", type=int, default=16384, help="configurations per GPU")
-    ap.add_argument("--precision", default="fp32")
+    ap.add_argument("--precision", default=host.DEFAULT_PRECISION, choices=list(host.VERIFIED_PRECISIONS),
+                    help="arithmetic of the kernels (fp64 is not verified on the GPU and not offered)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the Atlas-30 workloads reported under 'secondary'")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall seconds of the cpu_baseline sample (whole passes)")
-    ap.add_argument("--cpu-cores", type=int, default=0, help="worker processes of the cpu_baseline (0 = all cores of this process, at most 16)")
+    ap.add_argument("--cpu-cores", type=int, default=0, help="worker processes of the cpu_baseline (0 = every core this process may use)")
     ap.add_argument("--prewarm-s", type=float, default=0.3, help="seconds of untimed launches before the warm-up (clock ramp)")
     ap.add_argument("--blocks", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--split", type=int, default=0, help="column-split factor of the gradient kernel: 0 auto, 1 never, S force")
+    ap.add_argument("--coop", type=int, default=0, help="tile-cooperative gradient kernel: 0 auto, 1 never, 2 always")
     ap.add_argument("--all-kernels", action="store_true", help="also time the other four kernels (reported under 'kernels')")
     args = ap.parse_args()
-
-    from gridcodegenerator_amd import host, sharding
-    from gridcodegenerator_amd.robots import get_robot
 
     rank, local_rank, world = sharding.env_rank()
     # CPU baseline first: its worker processes are forked before this process initialises the GPU runtime
@@ -120,7 +252,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         n0 = get_robot(args.robot).get_num_joints()
         q0, qd0, u0 = make_inputs(n0, args.batch, 3 + rank)
-        cores = args.cpu_cores if args.cpu_cores > 0 else min(16, len(os.sched_getaffinity(0)))
+        cores = args.cpu_cores if args.cpu_cores > 0 else host_cores()[0]
         cpu_line = cpu_baseline(args.robot, q0, qd0, u0, args.cpu_seconds, cores)
 
     import torch
@@ -135,83 +267,42 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = sharding.init_distributed("gloo" if rehearsal else "nccl")
+    reduce_device = "cpu" if rehearsal else "cuda"
 
-    host.build_library(args.robot, args.precision)
-    h = host.GridHandle(args.robot, device=local_rank, precision=args.precision)
-    n, K = h.n, args.batch
-    # every rank owns an independent slice of the global batch (seed differs per rank)
-    q, qd, u = make_inputs(n, K, 3 + rank)
-    x = np.ascontiguousarray(np.concatenate([q, qd, u], axis=1))
-    d_in = torch.from_numpy(x).cuda()
-    d_out = torch.empty((K, 2 * n * n), dtype=torch.float32, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
-    h.set_split(host.ALG_FD_DU, args.split)
-    split_used = h.get_split(host.ALG_FD_DU, K)
+    # ---- headline workload: every rank owns an independent slice of the global batch (seed differs per rank)
+    w = Workload(torch, host, args.robot, args.batch, args.precision, local_rank, 3 + rank, args.blocks, args.threads, args.split, args.coop)
+    w.prewarm(args.prewarm_s)
+    main_line = w.measure(sharding, dist, args.steps, args.warmup, world, reduce_device)
+    kernels = w.all_kernels() if (args.all_kernels and rank == 0) else None
+    w.close()
 
-    def step():
-        h.forward_dynamics_gradient_device(d_out.data_ptr(), d_in.data_ptr(), 3 * n, K, gravity=GRAVITY,
-                                           blocks=args.blocks, threads=args.threads, stream=stream)
-
-    # Bring the GPU out of its idle power state first (an MI355X box idles in a low-power state and the default run is only
-    # ~3 ms of kernels): launch the same step for --prewarm-s seconds of wall clock.  Not counted as warm-up or steps.
-    t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < args.prewarm_s:
-        for _ in range(50):
-            step()
-        torch.cuda.synchronize()
-
-    elapsed = sharding.timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, dist, reduce_device="cpu" if rehearsal else "cuda")
-
-    # in-stream kernel duration (HIP events recorded on the launch stream by the C ABI)
-    kern_ms = h.time_device(host.ALG_FD_DU, d_out.data_ptr(), d_in.data_ptr(), 3 * n, K, gravity=GRAVITY,
-                            blocks=args.blocks, threads=args.threads, stream=stream, reps=max(20, min(args.steps, 200)))   # average over reps
-    finite = bool(torch.isfinite(d_out).all().item())
+    # ---- secondary workloads (north_star: "... iiwa-7 and Atlas-30 at batch 16k on 1 GPU and batch-sharded at 2/4/8 GPUs";
+    #      BASELINE config 5: Atlas-30, 1,048,576 configurations over 8 GPUs = 131072 per GPU)
+    secondary = {}
+    if not args.no_secondary and args.robot == "iiwa7" and args.batch == 16384:
+        plan = [("atlas30_batch16384", "atlas30", 16384, min(args.steps, 50), min(args.warmup, 5))]
+        if world > 1:
+            plan.append(("atlas30_batch131072_per_gpu", "atlas30", 131072, min(args.steps, 10), min(args.warmup, 2)))
+        for (key, robot, K, steps, warmup) in plan:
+            w2 = Workload(torch, host, robot, K, args.precision, local_rank, 5 + rank)
+            w2.prewarm(min(args.prewarm_s, 0.2))
+            line = w2.measure(sharding, dist, steps, warmup, world, reduce_device)
+            w2.close()
+            secondary[key] = line
 
     if rank == 0:
-        value = sharding.aggregate_throughput(K, world, args.steps, elapsed)
-        traffic = None      # PMC counters cannot be read from inside the timed process; use the committed rocprofv3 pass
-        try:
-            with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as fh:
-                traffic = json.load(fh).get("%s:%d:forward_dynamics_gradient" % (args.robot, K), {}).get("bytes")
-        except OSError:
-            pass
-        alg_bytes = host.algorithmic_bytes(host.ALG_FD_DU, n) * K
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        attrs = h.L.kernel_attributes(host.ALG_FD_DU)
-        out = {
-            "metric": "FD-gradient evals/sec (iiwa-7, batch=16k) + achieved HBM GB/s vs peak" if args.robot == "iiwa7" and K == 16384
-                      else "FD-gradient evals/sec (%s, batch=%d)" % (args.robot, K),
-            "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": h.L.compute_dtype, "data": "synthetic",
-            "config": {"workload": "%s forward_dynamics_gradient_kernel, batch %d per GPU, fp32 I/O, device-resident (reference _compute_only)"
-                                   % (args.robot, K),
-                       "robot": args.robot, "num_joints": n, "batch_per_gpu": K, "global_batch": K * world,
-                       "parallelism": "batch-sharded x%d, independent streams, no collective on the data path" % world,
-                       "launch": {"blocks": args.blocks or "suggested", "threads": args.threads or h.L.constants["SUGGESTED_THREADS"],
-                                  "column_split": split_used},
-                       "kernel": {"vgprs": attrs["numRegs"], "scratch_bytes_per_lane": attrs["scratch_bytes_per_lane"]},
-                       "outputs_finite": finite},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, profiles/)", "kernel": "forward_dynamics_gradient_kernel", "kernel_avg_us": 1e3 * kern_ms,
-                         "traffic_GBps": (traffic / (kern_ms * 1e-3) / 1e9) if traffic else None,
-                         "traffic_frac": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
-                         "algorithmic_bytes_per_eval": host.algorithmic_bytes(host.ALG_FD_DU, n),
-                         "kernel_evals_per_s": K / (kern_ms * 1e-3)},
-        }
-        if args.all_kernels:
-            kern = {}
-            bufs = {a: torch.empty((K, host.output_size(a, n)), dtype=torch.float32, device="cuda") for a in range(5)}
-            for a in range(5):
-                h.time_device(a, bufs[a].data_ptr(), d_in.data_ptr(), 3 * n, K, gravity=GRAVITY, stream=stream, reps=200)   # ramp
-                ms = h.time_device(a, bufs[a].data_ptr(), d_in.data_ptr(), 3 * n, K, gravity=GRAVITY, stream=stream, reps=200)
-                by = host.algorithmic_bytes(a, n) * K
-                kern[host.ALG_NAMES[a]] = {"avg_us": 1e3 * ms, "evals_per_s": K / (ms * 1e-3), "alg_GBps": by / (ms * 1e-3) / 1e9}
-            out["kernels"] = kern
+        K = args.batch
+        out = {"metric": HEADLINE_METRIC if (args.robot == "iiwa7" and K == 16384) else "FD-gradient evals/sec (%s, batch=%d)" % (args.robot, K),
+               "value": main_line["value"], "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": main_line["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": main_line["dtype"], "data": "synthetic", "config": main_line["config"], "roofline": main_line["roofline"]}
+        if secondary:
+            out["secondary"] = secondary
+        if kernels:
+            out["kernels"] = kernels
         if cpu_line is not None:
             out["cpu_baseline"] = cpu_line
         print(json.dumps(out), flush=True)
-    h.close()
     if dist is not None:
         dist.destroy_process_group()
 

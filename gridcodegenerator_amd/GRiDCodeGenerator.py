@@ -8,34 +8,26 @@ gfx950 with one wavefront lane per configuration, not the refere
 one-block-per-configuration CUDA.
 
 Generation-time knobs that have no reference counterpart are keyword-only:
-    precision        "fp32" | "fp64"  compute type C used for T=float (I/O stays T)
+    precision        "fp32" | "mixed" | "fp64"  arithmetic of the kernels for T=float (I/O stays T).  "fp32": compute type
+                                      C = float.  "mixed": C = float, but the Minv recursion and qdd = Minv (u - c) -- the parts
+                                      whose round-off cond(M) amplifies -- run in double.  "fp64" (C = double) is correct on the
+                                      host but NOT verified on the GPU: needs allow_unverified=True
     trig             "fast" | "libm" | "f64"   inline float sincos (default), library sincosf, or double then rounded
                                       as the reference does (helpers/_topology_helpers.py:127-128)
-    suggested_threads                 threads per block the LDS counts are sized for (multiple of 64)
+    suggested_threads, max_threads    threads per block the LDS counts are sized for (multiple of 64) / __launch_bounds__
+    suggested_max_blocks              grid size cap of the host wrappers (larger batches grid-stride)
     out_chunk                         max values per configuration staged in LDS per coalesced flush
-    emit_order       "demand" | "creation"  ordering of the straight-line bodies
     emit_inner_api                    also emit the pointer-style ``_inner`` tier (API parity)
-    out_mode         "staged" | "direct"  LDS-staged flat stores (default) or per-lane row stores for kernel outputs.
-                                      Measured (iiwa-7 FD gradient): staged 12.5 us vs direct 15.0 us at K=16384 (split 3),
-                                      75 us vs 126 us at K=262144 -- strided 4-byte stores become the bottleneck.
-    packed                            EXPERIMENTAL: emit the (d/dq, d/dqd) gradient recursions as packed pairs
-                                      (v_pk_fma_f32).  Halves the fp instruction count (6777 -> 4818 for iiwa-7) but hipcc
-                                      allocates the 64-bit pairs badly (512 registers + spills): 29 us vs 17 us.  Off.
     pipeline         "auto" | bool    also emit the two-pass (workspace) variants of the gradient kernels; auto: n > 12
     grad_schedule    "auto" | "fused" | "recompute"   body of the single-kernel gradient cores: demand-ordered fused trace, or
-                     column-serial with per-column recomputation of v, a, f (no spills for large robots); auto: recompute for n > 12
-    grad_table       bool             recompute schedule only: park sin q, cos q, qd, qdd in a per-wave LDS table and re-load them per
-                     column instead of keeping them in registers (Atlas-30: no scratch at all, but 16 % more instructions and
-                     measured slower: 186 vs 163 us at K = 32768) -- off by default, exercised by the mixed5 test robot
-    split_sets       bool             column groups of the S >= 3 split kernels may be arbitrary column SETS (exact exhaustive
-                     partition, cores.optimal_column_sets: iiwa-7 dFD x4 worst group 3580 -> 2937 ops).  Measured: 9.4 vs 10.1 us at
-                     K=4096 but 12.05 vs 11.46 us at K=16384 (one flush per column instead of one per group half) -- off by default
-    split_fences     bool             scheduling fence after every output store also in the S >= 3 split kernels (without: 13.0 vs 12.0 us)
-    waves_per_simd                    __launch_bounds__ occupancy hint for the unsplit kernels (caps registers at 512/w)
+                     column-serial with per-column recomputation of v, a, f (large robots); auto: recompute for n > 12.
+                     "fused" with n > 12 miscomputed on the GPU: needs allow_unverified=True
     grad_splits      "auto" | list    column-split variants of the two gradient kernels to emit (small-batch speed)
-    fence_every                       extra scheduling fence every N emitted statements (0 = none).  A fence always
-                                      follows each output store: without it hipcc's machine scheduler hoists every
-                                      output's dot product above the stores (iiwa-7 FD gradient: 472 vs 257 registers)
+    waves_per_simd                    __launch_bounds__ occupancy hint for the unsplit kernels (caps registers at 512/w);
+                                      > 1 with n > 12 reproduces the register-capped builds that faulted: needs allow_unverified=True
+    allow_unverified bool             accept the combinations above that are known-bad or unverified on the GPU (for debugging them)
+    experimental     dict             measured-and-rejected or test-only variants, NOT part of the supported surface
+                                      (defaults in EXPERIMENTAL_DEFAULTS; each is described and its measurement quoted there)
 """
 from .algorithms._emit import AlgorithmEmitMixin
 from .emit.model import RobotSpec
@@ -45,17 +37,56 @@ from .verification import VerificationMixin
 
 
 class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin, VerificationMixin):
+    # Experiments that were built, measured on MI355X and rejected (or that exist for the tests only).  Kept reachable through
+    # ``experimental={...}`` so the measurements in DESIGN.md stay reproducible; none of them is a supported option.
+    EXPERIMENTAL_DEFAULTS = dict(
+        emit_order="demand",    # "creation": nodes in trace order (the recomputing cores always use it)
+        fence_every=0,          # extra scheduling fence every N statements (a fence always follows each output store: without it
+                                # hipcc hoists every output's dot product above the stores, iiwa-7 dFD 472 vs 257 registers)
+        out_mode="staged",      # "direct": per-lane row stores instead of LDS-staged flat stores (15.0 vs 12.5 us at K=16384)
+        packed=False,           # (d/dq, d/dqd) recursions as v_pk_fma_f32 pairs: 6777 -> 4818 instructions but 512 registers + spills
+        grad_table=False,       # recompute schedule: sin q, cos q, qd, qdd in a per-wave LDS table (Atlas-30: 186 vs 163 us); mixed5 tests it
+        split_fences=True,      # scheduling fence after every output store also in the S >= 3 split kernels (without: 13.0 vs 12.0 us)
+        split_sets=False,       # column groups of the S >= 3 splits as arbitrary column sets (12.05 vs 11.46 us at K=16384); mixed5 tests it
+        fence_stride=1,         # fence after every N-th store instead of every store (12-15 % slower, spills)
+        dot_ways=1,             # dot products over w interleaved accumulators (0-4 % slower)
+        split_cap=(2,),         # which split factors are register-capped to two waves per SIMD (small robots only)
+    )
+
     def __init__(self, robotObj, DEBUG_MODE=False, NEED_PRINT_MAT=False, USE_DYNAMIC_SHARED_MEM=True,
                  FILE_NAMESPACE="grid", *, precision="fp32", trig="fast", suggested_threads=64, max_threads=256,
-                 out_chunk=64, emit_order="demand", emit_inner_api=True, suggested_max_blocks=2048, fence_every=0, grad_splits="auto", out_mode="staged", packed=False, waves_per_simd=1, pipeline="auto", grad_schedule="auto", grad_table=False, split_fences=True, split_sets=False, fence_stride=1, dot_ways=1, split_cap=(2,)):
-        if precision not in ("fp32", "fp64"):
-            raise ValueError("precision must be 'fp32' or 'fp64'")
+                 suggested_max_blocks=2048, out_chunk=64, emit_inner_api=True, pipeline="auto", grad_schedule="auto",
+                 grad_splits="auto", waves_per_simd=1, allow_unverified=False, experimental=None):
+        if precision not in ("fp32", "mixed", "fp64"):
+            raise ValueError("precision must be 'fp32', 'mixed' or 'fp64'")
         if trig not in ("fast", "libm", "f64"):
             raise ValueError("trig must be 'fast', 'libm' or 'f64'")
         if suggested_threads % 64 != 0 or not (64 <= suggested_threads <= max_threads <= 1024):
             raise ValueError("need 64 <= suggested_threads <= max_threads <= 1024, suggested_threads a multiple of 64")
+        if grad_schedule not in ("auto", "fused", "recompute"):
+            raise ValueError("grad_schedule must be 'auto', 'fused' or 'recompute'")
+        exp = dict(self.EXPERIMENTAL_DEFAULTS)
+        unknown = set(experimental or {}) - set(exp)
+        if unknown:
+            raise ValueError("unknown experimental option(s): %s" % sorted(unknown))
+        exp.update(experimental or {})
+        if exp["out_mode"] not in ("direct", "staged"):
+            raise ValueError("out_mode must be 'direct' or 'staged'")
         self.robot = robotObj
         self.spec = RobotSpec(robotObj)
+        large = self.spec.n > 12
+        # combinations that faulted, hung or miscomputed on the GPU are refused at generation time
+        if not allow_unverified:
+            if precision == "fp64":
+                raise ValueError("precision='fp64' kernels are unverified on the GPU (wrong results / hangs in round 1); use "
+                                 "'mixed' (double where cond(M) amplifies) or pass allow_unverified=True")
+            if large and grad_schedule == "fused":
+                raise ValueError("grad_schedule='fused' with %d joints miscomputed on the GPU (spilled 2.5-4.7 KB per lane); "
+                                 "use 'recompute' or pass allow_unverified=True" % self.spec.n)
+            if large and int(waves_per_simd) > 1:
+                raise ValueError("waves_per_simd > 1 with %d joints reproduces the register-capped kernels that faulted on the GPU; "
+                                 "pass allow_unverified=True to build them anyway" % self.spec.n)
+        self.allow_unverified = bool(allow_unverified)
         self._chunks = []
         self.indent_level = 0
         self.DEBUG_MODE = DEBUG_MODE
@@ -69,23 +100,20 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin, Verific
         self.max_threads = int(max_threads)
         self.suggested_max_blocks = int(suggested_max_blocks)
         self.out_chunk = int(out_chunk)
-        self.emit_order = emit_order
-        self.fence_every = int(fence_every)
         self.grad_splits = grad_splits
-        if out_mode not in ("direct", "staged"):
-            raise ValueError("out_mode must be 'direct' or 'staged'")
-        self.out_mode = out_mode
-        self.packed = bool(packed)
         self.waves_per_simd = int(waves_per_simd)
-        self.use_pipeline = (self.spec.n > 12) if pipeline == "auto" else bool(pipeline)
-        assert grad_schedule in ("auto", "fused", "recompute")
-        self.grad_schedule = ("recompute" if self.spec.n > 12 else "fused") if grad_schedule == "auto" else grad_schedule
-        self.grad_table = bool(grad_table) and self.grad_schedule == "recompute"
-        self.split_fences = bool(split_fences)
-        self.split_sets = bool(split_sets)
-        self.fence_stride = int(fence_stride)
-        self.dot_ways = int(dot_ways)
-        self.split_cap = tuple(int(x) for x in split_cap)
+        self.use_pipeline = large if pipeline == "auto" else bool(pipeline)
+        self.grad_schedule = ("recompute" if large else "fused") if grad_schedule == "auto" else grad_schedule
+        self.emit_order = exp["emit_order"]
+        self.fence_every = int(exp["fence_every"])
+        self.out_mode = exp["out_mode"]
+        self.packed = bool(exp["packed"])
+        self.grad_table = bool(exp["grad_table"]) and self.grad_schedule == "recompute"
+        self.split_fences = bool(exp["split_fences"])
+        self.split_sets = bool(exp["split_sets"])
+        self.fence_stride = int(exp["fence_stride"])
+        self.dot_ways = int(exp["dot_ways"])
+        self.split_cap = tuple(int(x) for x in exp["split_cap"])
         self.kernel_instances = []
         self.split_stats = {}
         self.emit_inner_api = bool(emit_inner_api)
@@ -127,11 +155,19 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin, Verific
                                       "(algorithms/_inverse_dynamics.py:391) and has no place in a lane-per-configuration design")
         if include_base_inertia:
             raise NotImplementedError("include_base_inertia adds data no reference emitter reads (helpers/_topology_helpers.py:5-12)")
+        from .emit.trace import Tracer
+        saved = (Tracer.use_packed, Tracer.mixed, Tracer.dot_ways)
+        Tracer.use_packed = self.packed
+        Tracer.mixed = (self.precision == "mixed")
+        Tracer.dot_ways = self.dot_ways
+        try:
+            self._gen_all_code_body(use_thread_group, include_base_inertia)
+        finally:
+            Tracer.use_packed, Tracer.mixed, Tracer.dot_ways = saved
+
+    def _gen_all_code_body(self, use_thread_group, include_base_inertia):
         self._chunks = []
         self.indent_level = 0
-        from .emit.trace import Tracer
-        Tracer.use_packed = self.packed
-        Tracer.dot_ways = self.dot_ways
         self.core_stats = {}
         self.trace_stats = {}
         self.kernel_instances = []
@@ -173,6 +209,9 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin, Verific
             "    __global__ forward_dynamics_gradient_kernel<T>(T *d_df_du, const T *d_q_qd, const int stride_q_qd, const T *d_qdd, const T *d_Minv, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS)",
             "    __host__   forward_dynamics_gradient<T,USE_QDD_MINV_FLAG=false>(gridData<T> *hd_data, const robotModel<T> *d_robotModel, const T gravity, const int num_timesteps, const dim3 block_dimms, const dim3 thread_dimms, hipStream_t *streams)",
             "",
+            "    __global__ forward_dynamics_gradient_rollout_kernel<T>(T *d_traj, const T *d_x0, const T *d_u_traj, const T dt, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS, const int NUM_STEPS)",
+            "               (no reference counterpart: a consumer of the forward-dynamics gradient -- semi-implicit Euler rollout that writes x+, A, B per step)",
+            "",
             "Every host function also exists as <name>_compute_only(...) (device-resident I/O, no streams argument) and",
             "<name>_launch(..., hipStream_t stream) (asynchronous, no synchronisation).",
             "",
@@ -203,6 +242,8 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin, Verific
         self.gen_forward_dynamics(use_thread_group)
         self.gen_inverse_dynamics_gradient(use_thread_group)
         self.gen_forward_dynamics_gradient(use_thread_group)
+        self.gen_forward_dynamics_gradient_coop(use_thread_group)
+        self.gen_forward_dynamics_gradient_rollout(use_thread_group)
         self.gen_init_close_grid()
         self.gen_add_end_control_flow()
         self.gen_kernel_instance_list()

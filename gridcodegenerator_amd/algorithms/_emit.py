@@ -41,10 +41,14 @@ class AlgorithmEmitMixin:
             "FD": dict(inputs=[("q_qd_u", 3 * n)], n_out=n),
             "ID_DU": dict(inputs=[("q_qd", 2 * n), ("qdd", n)], n_out=2 * n * n),
             "FD_DU": dict(inputs=[("q_qd_u", 3 * n), ("qdd", n), ("Minv", n * n)], n_out=2 * n * n),
+            # rollout consumer: x0 (2n) and u_t (n) in, rows of [x+ | A | B] out in chunks of 2n
+            "ROLLOUT": dict(inputs=[("x0", 2 * n), ("u", n)], n_out=cores.rollout_row_count(self.spec)),
         }
         for (alg, d) in lay.items():
             d["chunk"] = chunk(d["n_out"])
             d["in_piece"] = MAX_IN_PIECE
+            if alg == "ROLLOUT":
+                d["chunk"] = 2 * n      # x+, one column of A or one column of B per flush
             if self.grad_schedule == "recompute" and alg in ("ID_DU", "FD_DU"):
                 d["chunk"] = n          # one gradient column per flush
             if self.grad_table and alg in ("ID_DU", "FD_DU"):
@@ -72,6 +76,7 @@ class AlgorithmEmitMixin:
         self.gen_add_code_line(qualifiers)
         self.gen_add_code_line(signature + " {", True)
         self.gen_add_code_line("typedef C C2 __attribute__((ext_vector_type(2)));   // packed pair (d/dq, d/dqd): v_pk_* on gfx950")
+        self.gen_add_code_line("typedef double D;   // high-precision type of the mixed-precision regions (Minv recursion, qdd = Minv (u - c))")
         ind = "    " * self.indent_level
         lines = tracer.emit(indent=ind, order=order or self.emit_order, store=store, fence_every=self.fence_every, fence_stmt=fence_stmt)
         self.gen_add_raw("\n".join(lines))
@@ -95,8 +100,20 @@ class AlgorithmEmitMixin:
             "template <typename T, typename C, typename In, typename Out>",
             "__host__ __device__ __forceinline__",
             "void %s(const In &in, Out &out, const T gravity)" % name, tracer,
-            store=lambda dst, val: ("in.tab_put(%s, (T)(%s));" % (dst[4:], val)) if isinstance(dst, str) and dst.startswith("tab:")
-            else "out.put(%s, (T)(%s));%s" % (dst, val, fence_after_store()), order=order, fence_stmt=fence_stmt)
+            store=lambda dst, val: self._core_store(dst, val, fence_after_store), order=order, fence_stmt=fence_stmt)
+
+    @staticmethod
+    def _core_store(dst, val, fence_after_store):
+        if isinstance(dst, str):
+            if dst.startswith("tab:"):
+                return "in.tab_put(%s, (T)(%s));" % (dst[4:], val)
+            if dst.startswith("xch:"):
+                return "in.xch_put(%s, (T)(%s));" % (dst[4:], val)
+            if dst == "barrier":
+                return "GRID_SCHED_FENCE(); in.barrier(); GRID_SCHED_FENCE();"
+            if dst == "anchor":
+                return "GRID_KEEP(%s);" % val
+        return "out.put(%s, (T)(%s));%s" % (dst, val, fence_after_store())
 
     def _emit_load(self, dst, src, total, stride, piece=MAX_IN_PIECE):
         off = 0
@@ -460,6 +477,17 @@ class AlgorithmEmitMixin:
         self.gen_add_code_line("default: return false;")
         self.gen_add_end_control_flow()
         self.gen_add_end_function()
+        # resources of a split kernel (what a dispatch of it really uses: bench.py reports these)
+        self.gen_add_func_doc("hipFuncGetAttributes of a column-split variant of %s" % kernel_base, ["returns false for an unsupported split"], [], None)
+        self.gen_add_code_line("template <typename T>")
+        self.gen_add_code_line("__host__ inline")
+        self.gen_add_code_line("bool %s_split_attributes(const int split, hipFuncAttributes *attr) {" % kernel_base.replace("_kernel", ""), True)
+        self.gen_add_code_line("switch (split){", True)
+        for (S, parts, worst) in chosen:
+            self.gen_add_code_line("case %d: gpuErrchk(hipFuncGetAttributes(attr, reinterpret_cast<const void *>(&%s_split%d<T>))); return true;" % (S, kernel_base, S))
+        self.gen_add_code_line("default: return false;")
+        self.gen_add_end_control_flow()
+        self.gen_add_end_function()
 
     def _emit_host(self, alg, name, doc, template, has_gravity, body_pre, launches, body_post, timing_label):
         """Host wrappers: mode 0 (copies + launch, reference semantics), _compute_only (mode 2) and an
@@ -771,7 +799,9 @@ class AlgorithmEmitMixin:
                                    "template <typename T, typename C = typename grid_compute<T>::type>",
                                    "__host__ __device__ __forceinline__",
                                    "void inverse_dynamics_gradient_inner(T *s_dc_du, const T *s_q, const T *s_qd, const T *s_vaf, T *s_XImats, T *s_temp, const T gravity)",
-                                   cores.inner_inverse_dynamics_gradient(self.spec))
+                                   cores.inner_inverse_dynamics_gradient_columns(self.spec) if self.grad_schedule == "recompute"
+                                   else cores.inner_inverse_dynamics_gradient(self.spec),
+                                   order="creation" if self.grad_schedule == "recompute" else None)
 
     def gen_inverse_dynamics_gradient_device(self, use_thread_group=False, use_qdd_input=False):
         self.gen_add_func_doc("Computes the gradient of inverse dynamics", [] if use_qdd_input else ["optimized for qdd = 0"], [], None)
@@ -930,3 +960,236 @@ class AlgorithmEmitMixin:
         else:
             self._emit_no_pipeline("FD_DU", "forward_dynamics_gradient", "df_du", ("q_qd_u", 3 * n, "stride_q_qd_u"))
         self.gen_forward_dynamics_gradient_host()
+
+    # ------------------------------------------------------------------------------------------
+    # rollout consumer of the forward-dynamics gradient
+    # ------------------------------------------------------------------------------------------
+    def gen_forward_dynamics_gradient_rollout(self, use_thread_group=False):
+        """A downstream consumer of the forward-dynamics gradient: the reference ships the `_device` tier so that user kernels
+        can keep a trajectory on-chip (README.md:26-29, algorithms/_forward_dynamics_gradient.py:59-99) but contains no such
+        kernel.  One lane integrates ONE trajectory with semi-implicit Euler for NUM_STEPS steps; q, qd never leave the lane's
+        registers between steps; every step writes the next state and the discrete-time linearisation (A, B)."""
+        n = self.spec.n
+        row = cores.rollout_row_count(self.spec)
+        if self.grad_schedule == "recompute":
+            bases = []
+            tr = cores.core_gradient_recompute(self.spec, "fd", rollout=bases)
+            order = "creation"
+        else:
+            tr, bases = cores.core_rollout_step(self.spec)
+            order = None
+        self.gen_add_code_line("const int ROLLOUT_ROW_COUNT = %d; // values per configuration and step: [x+ (%d) | A (%d x %d, column-major) | B (%d x %d)]"
+                               % (row, 2 * n, 2 * n, 2 * n, 2 * n, n))
+        self.gen_add_code_line("const int ROLLOUT_DYNAMIC_SHARED_MEM_COUNT = %d;" % ((self.max_threads // WAVE) * self.lds_per_wave("ROLLOUT")))
+        self._emit_core("forward_dynamics_gradient_rollout_step_core",
+                        "One semi-implicit Euler step of the forward dynamics and its linearisation: qdd = FD(q, qd, u); qd+ = qd + dt qdd; "
+                        "q+ = q + dt qd+; A = dx+/dx, B = dx+/du (x = [q; qd]); out = chunks of %d values, chunk k at row offset BASES[k]" % (2 * n),
+                        tr, order=order)
+        self.kernel_instances.append("__global__ void @NS::forward_dynamics_gradient_rollout_kernel<T>(T *, const T *, const T *, const T, "
+                                     "const @NS::robotModel<T> *, const T, const int, const int);")
+        self.gen_add_func_doc("Trajectory rollout with linearisation (consumer of the forward-dynamics gradient)",
+                              ["lane-per-trajectory: the state stays in registers across the NUM_STEPS steps",
+                               "d_traj is TIME-MAJOR: d_traj[(t*NUM_TIMESTEPS + k)*ROLLOUT_ROW_COUNT + ...] = [x_{t+1} | A_t | B_t] of trajectory k",
+                               "d_u_traj is time-major too: d_u_traj[(t*NUM_TIMESTEPS + k)*NUM_JOINTS + j]",
+                               "launch with ROLLOUT_DYNAMIC_SHARED_MEM_COUNT*sizeof(T) of dynamic LDS (or grid_lds_bytes for smaller blocks)"],
+                              ["d_traj is the output, NUM_STEPS*NUM_TIMESTEPS*ROLLOUT_ROW_COUNT values",
+                               "d_x0 holds the initial states [q | qd], %d values per trajectory (dense)" % (2 * n),
+                               "d_u_traj holds the input torques", "dt is the integration step",
+                               "d_robotModel is the pointer to the initialized model specific helpers on the GPU (unused: constants are baked in)",
+                               "gravity is the gravity constant", "NUM_TIMESTEPS is the number of trajectories (the batch)",
+                               "NUM_STEPS is the number of integration steps"], None)
+        self.gen_add_code_line("template <typename T, typename C = typename grid_compute<T>::type>")
+        self.gen_add_code_line("__global__ __launch_bounds__(GRID_MAX_THREADS)")
+        self.gen_add_code_line("void forward_dynamics_gradient_rollout_kernel(T *d_traj, const T *d_x0, const T *d_u_traj, const T dt, "
+                               "const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS, const int NUM_STEPS) {", True)
+        self.gen_add_code_lines([
+            "extern __shared__ __align__(16) unsigned char s_grid_dyn[];",
+            "const grid_tile_iter it(NUM_TIMESTEPS);",
+            "T *s_wave = reinterpret_cast<T *>(s_grid_dyn) + it.wave_in_block*%d;" % self.lds_per_wave("ROLLOUT"),
+            "for (int k0 = it.k0_first; k0 < NUM_TIMESTEPS; k0 += it.k0_step){",
+        ])
+        self.indent_level += 1
+        self.gen_add_code_line("T s_x[%d];" % (2 * n))
+        self._emit_load("s_x", "d_x0", 2 * n, str(2 * n))
+        self.gen_add_code_line("for (int t = 0; t < NUM_STEPS; t++){", True)
+        self.gen_add_code_line("T s_u[%d]; T s_xn[%d];" % (n, 2 * n))
+        self._emit_load("s_u", "(d_u_traj + (size_t)t*NUM_TIMESTEPS*%d)" % n, n, str(n))
+        self.gen_add_code_line("const grid_in_ptrs<T> in = {s_x, s_x + %d, s_u, nullptr, nullptr, nullptr, dt};" % n)
+        self.gen_add_code_line("grid_out_chunks<T,%d,%d,%s> out = {s_wave, d_traj + (size_t)t*NUM_TIMESTEPS*%d, k0, it.lane, it.W, NUM_TIMESTEPS, s_xn};"
+                               % (row, 2 * n, ",".join(str(b) for b in bases), row))
+        self.gen_add_code_line("forward_dynamics_gradient_rollout_step_core<T,C>(in, out, gravity);")
+        self.gen_add_code_line("#pragma unroll")
+        self.gen_add_code_line("for (int i = 0; i < %d; i++){s_x[i] = s_xn[i];}" % (2 * n))
+        self.gen_add_end_control_flow()
+        self.gen_add_end_control_flow()
+        self.gen_add_end_function()
+        self.gen_add_func_doc("Launch the rollout kernel (asynchronous, on `stream`)", ["illegal launch shapes are replaced by the suggested one"], [], None)
+        self.gen_add_code_line("template <typename T>")
+        self.gen_add_code_line("__host__ inline")
+        self.gen_add_code_line("void forward_dynamics_gradient_rollout_launch(T *d_traj, const T *d_x0, const T *d_u_traj, const T dt, const robotModel<T> *d_robotModel,")
+        self.gen_add_code_line("        const T gravity, const int num_timesteps, const int num_steps, const dim3 block_dimms, const dim3 thread_dimms, hipStream_t stream) {", True)
+        self.gen_add_code_lines([
+            "dim3 blocks, threads; grid_launch_dims(block_dimms, thread_dimms, num_timesteps, &blocks, &threads);",
+            "const size_t lds_bytes = grid_lds_bytes<T>(threads, %d);" % self.lds_per_wave("ROLLOUT"),
+            "forward_dynamics_gradient_rollout_kernel<T><<<blocks,threads,lds_bytes,stream>>>(d_traj,d_x0,d_u_traj,dt,d_robotModel,gravity,num_timesteps,num_steps);",
+            "gpuErrchk(hipGetLastError());",
+        ])
+        self.gen_add_end_function()
+
+    # ------------------------------------------------------------------------------------------
+    # tile-cooperative forward-dynamics gradient: the waves of a block share one tile of 64 configurations
+    # ------------------------------------------------------------------------------------------
+    COOP_WAVES = 4
+
+    def _coop_groups(self, builder, slots):
+        """Column groups of the cooperating waves: contiguous, balanced on (phase-1 work of the wave's role) + (traced cost of
+        its columns).  The producer (Minv) takes the LAST group -- late columns are the cheapest -- so that its longer
+        phase 1 is paid back by a shorter phase 2.  Returns [(role, cols)], producer first."""
+        n, W = self.spec.n, self.COOP_WAVES
+        roles = ["producer", "consumer_c"] + ["consumer"] * (W - 2)
+        ops = lambda role, cols: cores._arith_ops(builder(role, cols, slots))
+        single = {role: [ops(role, [c]) for c in range(n)] for role in ("producer", "consumer")}
+        base = {role: min(single[role]) for role in single}
+        marg = {role: [x - base[role] for x in single[role]] for role in single}
+
+        def cost(role, b, e):
+            r = "producer" if role == "producer" else "consumer"
+            return base[r] + sum(marg[r][b:e])
+        best = None
+        import itertools
+        for cuts in itertools.combinations(range(1, n), W - 1):
+            bounds = (0,) + cuts + (n,)
+            parts = [(bounds[i], bounds[i + 1]) for i in range(W)]
+            worst = max([cost("producer", *parts[-1])] + [cost("consumer", *p) for p in parts[:-1]])
+            if best is None or worst < best[0]:
+                best = (worst, parts)
+        parts = best[1]
+        groups = [("producer", list(range(*parts[-1])))]
+        for role, pr in zip(roles[1:], parts[:-1]):
+            groups.append((role, list(range(*pr))))
+        return groups
+
+    def gen_forward_dynamics_gradient_coop(self, use_thread_group=False):
+        """`forward_dynamics_gradient_kernel_coop`: one block of COOP_WAVES wavefronts per tile of 64 configurations.  The
+        column-split kernels repeat the shared prefix (X(q), Minv, RNEA) in every column group; here the waves of a block
+        SHARE it: one wave runs the Minv recursion while the others run RNEA, the results cross through LDS, and every wave
+        then differentiates its own group of columns.  Large robots also stop holding Minv in registers (it is read from LDS
+        where it is used), which is what made their column groups spill."""
+        n = self.spec.n
+        W = self.COOP_WAVES
+        if n < W:
+            self.gen_add_code_line("const int FD_DU_COOP_WAVES = 0; // no tile-cooperative kernel for this robot")
+            self._emit_no_coop()
+            return
+        slots = cores.CoopSlots(self.spec)
+        rec = (self.grad_schedule == "recompute")
+        if rec:
+            builder = lambda role, cols, sl: cores.core_gradient_recompute(self.spec, "fd", cols=cols, coop=(role, sl))
+        else:
+            builder = lambda role, cols, sl: cores.core_forward_dynamics_gradient_coop(self.spec, role, cols, sl)
+        groups = self._coop_groups(builder, slots)
+        n_out = self.io_layout["FD_DU"]["n_out"]
+        piece = min(32, max(16, n))                  # inputs staged in small pieces: small per-wave staging regions (Atlas-30:
+                                                     # 4 x 7.5 KB + 495 exchange slots x 256 B = 154 KB of the CU's 160 KB)
+        stage = WAVE * max(piece, n)                 # per wave: input pieces, and one gradient column per flush
+        xch_off = W * stage
+        lds_elems = xch_off + WAVE * slots.count
+        if 4 * lds_elems > 160 * 1024:
+            self.gen_add_code_line("const int FD_DU_COOP_WAVES = 0; // the exchange region of this robot does not fit the 160 KB of LDS")
+            self._emit_no_coop()
+            return
+        self.coop_stats = dict(groups=[(r, list(c)) for (r, c) in groups], slots=slots.count, lds_bytes=4 * lds_elems)
+        self.gen_add_code_line("const int FD_DU_COOP_WAVES = %d; // wavefronts per block of the tile-cooperative kernel (block = %d threads, one tile)" % (W, W * WAVE))
+        self.gen_add_code_line("const int FD_DU_COOP_SHARED_MEM_COUNT = %d; // dynamic LDS in T elements: %d staging regions + %d exchange slots x 64 lanes"
+                               % (lds_elems, W, slots.count))
+        names = []
+        for w, (role, cols) in enumerate(groups):
+            cname = "forward_dynamics_gradient_coop_core_w%d" % w
+            tr = builder(role, cols, slots)
+            self._emit_core(cname, "Tile-cooperative forward-dynamics gradient, wave %d of %d (%s): columns %s of d/dq and of d/dqd"
+                            % (w, W, role, list(cols)), tr, order="creation" if rec else None)
+            names.append((cname, cols))
+        self.kernel_instances.append("__global__ void @NS::forward_dynamics_gradient_kernel_coop<T>(T *, const T *, const int, "
+                                     "const @NS::robotModel<T> *, const T, const int);")
+        self.gen_add_func_doc("Computes the gradient of forward dynamics (tile-cooperative: %d wavefronts share each tile of 64 configurations)" % W,
+                              ["launch with EXACTLY %d threads per block and FD_DU_COOP_SHARED_MEM_COUNT*sizeof(T) of dynamic LDS" % (W * WAVE),
+                               "(use forward_dynamics_gradient_coop_launch); blocks grid-stride over the tiles",
+                               "wave roles and column groups: %s" % ["%s:%s" % (r, list(c)) for (r, c) in groups]],
+                              ["d_df_du is the output buffer, %d values per configuration" % n_out,
+                               "d_q_qd_u is the input buffer, %d values read per configuration" % (3 * n),
+                               "stride_q_qd_u is the stride between configurations in d_q_qd_u",
+                               "d_robotModel is the pointer to the initialized model specific helpers on the GPU (unused: constants are baked in)",
+                               "gravity is the gravity constant", "NUM_TIMESTEPS is the number of configurations"], None)
+        self.gen_add_code_line("template <typename T, typename C = typename grid_compute<T>::type>")
+        self.gen_add_code_line("__global__ __launch_bounds__(%d)" % (W * WAVE))
+        self.gen_add_code_line("void forward_dynamics_gradient_kernel_coop(T *d_df_du, const T *d_q_qd_u, const int stride_q_qd_u, "
+                               "const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS) {", True)
+        self.gen_add_code_lines([
+            "extern __shared__ __align__(16) unsigned char s_grid_dyn[];",
+            "grid_tile_iter it(NUM_TIMESTEPS);              // lane / wave bookkeeping only: the tile loop below is per BLOCK",
+            "T *s_wave = reinterpret_cast<T *>(s_grid_dyn) + it.wave_in_block*%d;" % stage,
+            "T *s_xch = reinterpret_cast<T *>(s_grid_dyn) + %d;" % xch_off,
+            "const int nblocks = gridDim.x*gridDim.y*gridDim.z;",
+            "const int bid = blockIdx.x + gridDim.x*(blockIdx.y + gridDim.y*blockIdx.z);",
+            "if (blockDim.x*blockDim.y*blockDim.z != %d){return;}    // (the launcher guarantees it; a wrong shape must not deadlock the barriers)" % (W * WAVE),
+            "for (int k0 = bid*GRID_WAVE_SIZE; k0 < NUM_TIMESTEPS; k0 += nblocks*GRID_WAVE_SIZE){",
+        ])
+        self.indent_level += 1
+        self.gen_add_code_line("T s_q_qd_u[%d];" % (3 * n))
+        self._emit_load("s_q_qd_u", "d_q_qd_u", 3 * n, "stride_q_qd_u", piece)
+        self.gen_add_code_line("const grid_in_coop<T> in = {s_q_qd_u, s_q_qd_u + %d, s_q_qd_u + %d, s_xch, it.lane};" % (n, 2 * n))
+        self.gen_add_code_line("switch (it.wave_in_block){", True)
+        for w, (cname, cols) in enumerate(names):
+            len0 = n * len(cols)
+            ch = n if rec else self._chunk_for(len0)
+            ch = min(ch, max(piece, n)) if 64 * ch > stage else ch
+            while len0 % ch != 0:
+                ch -= 1
+            assert 64 * ch <= stage
+            self.gen_add_code_line("case %d: {" % w, True)
+            self.gen_add_code_line("grid_out_staged<T,%d,%d,%d,%d,%d,%d> out = {s_wave, d_df_du, k0, it.lane, it.W, NUM_TIMESTEPS};"
+                                   % (n_out, 2 * len0, ch, n * cols[0], len0, n * n + n * cols[0]))
+            self.gen_add_code_line("%s<T,C>(in, out, gravity);" % cname)
+            self.gen_add_code_line("break;")
+            self.gen_add_end_control_flow()
+        self.gen_add_code_line("default: break;")
+        self.gen_add_end_control_flow()
+        self.gen_add_code_line("grid_block_sync();     // the exchange region is rewritten by the next tile")
+        self.gen_add_end_control_flow()
+        self.gen_add_end_function()
+        self.gen_add_func_doc("Launch the tile-cooperative forward-dynamics-gradient kernel (asynchronous, on `stream`)",
+                              ["tile_blocks <= 0: one block per tile of 64 configurations (capped at 4*SUGGESTED_MAX_BLOCKS)",
+                               "returns false when this robot has no tile-cooperative kernel"], [], None)
+        self.gen_add_code_line("template <typename T>")
+        self.gen_add_code_line("__host__ inline")
+        self.gen_add_code_line("bool forward_dynamics_gradient_coop_launch(T *d_df_du, const T *d_q_qd_u, const int stride_q_qd_u, const robotModel<T> *d_robotModel, "
+                               "const T gravity, const int num_timesteps, int tile_blocks, hipStream_t stream) {", True)
+        self.gen_add_code_lines([
+            "const size_t lds_bytes = (size_t)FD_DU_COOP_SHARED_MEM_COUNT*sizeof(T);",
+            "static thread_local int configured_device = -1;        // > 64 KiB of dynamic LDS must be enabled once per device",
+            "int dev = 0; gpuErrchk(hipGetDevice(&dev));",
+            "if (lds_bytes > 65536 && configured_device != dev){",
+            "    gpuErrchk(hipFuncSetAttribute(reinterpret_cast<const void *>(&forward_dynamics_gradient_kernel_coop<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));",
+            "    configured_device = dev;",
+            "}",
+            "const int tiles = (num_timesteps + GRID_WAVE_SIZE - 1)/GRID_WAVE_SIZE;",
+            "if (tile_blocks <= 0 || tile_blocks > tiles){tile_blocks = tiles;}",
+            "if (tile_blocks > 4*SUGGESTED_MAX_BLOCKS){tile_blocks = 4*SUGGESTED_MAX_BLOCKS;}",
+            "forward_dynamics_gradient_kernel_coop<T><<<dim3(tile_blocks,1,1),dim3(%d,1,1),lds_bytes,stream>>>(d_df_du,d_q_qd_u,stride_q_qd_u,d_robotModel,gravity,num_timesteps);" % (W * WAVE),
+            "gpuErrchk(hipGetLastError());",
+            "return true;",
+        ])
+        self.gen_add_end_function()
+        self.gen_add_func_doc("hipFuncGetAttributes of the tile-cooperative kernel", ["returns false when this robot has none"], [], None)
+        self.gen_add_code_line("template <typename T>")
+        self.gen_add_code_line("__host__ inline")
+        self.gen_add_code_line("bool forward_dynamics_gradient_coop_attributes(hipFuncAttributes *attr) {", True)
+        self.gen_add_code_line("gpuErrchk(hipFuncGetAttributes(attr, reinterpret_cast<const void *>(&forward_dynamics_gradient_kernel_coop<T>))); return true;")
+        self.gen_add_end_function()
+
+    def _emit_no_coop(self):
+        self.gen_add_code_line("const int FD_DU_COOP_SHARED_MEM_COUNT = 0;")
+        self.gen_add_code_lines(["template <typename T>", "__host__ inline",
+                                 "bool forward_dynamics_gradient_coop_launch(T *, const T *, const int, const robotModel<T> *, const T, const int, int, hipStream_t) {return false;}",
+                                 "template <typename T>", "__host__ inline",
+                                 "bool forward_dynamics_gradient_coop_attributes(hipFuncAttributes *) {return false;}", ""])

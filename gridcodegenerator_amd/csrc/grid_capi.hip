@@ -29,7 +29,8 @@ struct grid_handle {
     int max_timesteps;
     int split[5];   // per algorithm: 0 = auto, 1 = never split, S = force the S-way column-split kernel
     int pipeline[5];   // per algorithm: 0 = auto (single kernel), 1 = single kernel, 2 = two-pass (workspace) variant
-    T *d_workspace; size_t workspace_bytes;
+    int coop[5];       // per algorithm: 0 = auto, 1 = never, 2 = always the tile-cooperative kernel (where generated)
+    T *d_workspace; size_t workspace_bytes; hipStream_t workspace_stream; bool workspace_busy;
 };
 
 static thread_local std::string g_last_error;
@@ -61,7 +62,9 @@ extern "C" {
 const char *grid_robot_name(void) { return GRID_ROBOT_NAME; }
 int grid_num_joints(void) { return G::NUM_JOINTS; }
 int grid_topology_helpers_count(void) { return G::TOPOLOGY_HELPERS_COUNT; }
-const char *grid_compute_dtype(void) { return sizeof(G::grid_compute<float>::type) == 8 ? "f64" : "f32"; }
+#define GRID_DTYPE_CAT2(ns) GRID_DTYPE_##ns
+#define GRID_DTYPE_CAT(ns) GRID_DTYPE_CAT2(ns)
+const char *grid_compute_dtype(void) { return GRID_DTYPE_CAT(GRID_NS); }
 const char *grid_last_error(void) { return g_last_error.c_str(); }
 
 int grid_constants(int *out, int count) {
@@ -82,8 +85,8 @@ int grid_init(int device, grid_handle **out) {
     GRID_TRY(hipSetDevice(device), "grid_init: hipSetDevice");
     grid_handle *h = new grid_handle();
     h->device = device; h->hd_data = nullptr; h->max_timesteps = 0;
-    for (int a = 0; a < 5; a++) { h->split[a] = 0; h->pipeline[a] = 0; }
-    h->d_workspace = nullptr; h->workspace_bytes = 0;
+    for (int a = 0; a < 5; a++) { h->split[a] = 0; h->pipeline[a] = 0; h->coop[a] = 0; }
+    h->d_workspace = nullptr; h->workspace_bytes = 0; h->workspace_stream = nullptr; h->workspace_busy = false;
     h->d_robotModel = G::init_robotModel<T>();
     h->streams = G::init_grid<T>();
     if (int rc = grid_check("grid_init")) { delete h; return rc; }
@@ -232,6 +235,21 @@ static int effective_split(const grid_handle *h, int alg, int K) {
     return best;
 }
 
+// Tile-cooperative kernel (forward-dynamics gradient): 4 waves share a tile, the prefix (Minv | RNEA) is computed once per tile.
+// GRID_COOP_AUTO_MAX_TILES: largest batch (in tiles of 64) for which the automatic choice dispatches it -- set from the
+// measurements in profiles/ (see DESIGN.md section 3); 0 = only on request.
+#ifndef GRID_COOP_AUTO_MAX_TILES
+#define GRID_COOP_AUTO_MAX_TILES 0
+#endif
+static bool coop_available(int alg) { return alg == GRID_ALG_FD_DU && G::FD_DU_COOP_WAVES > 0; }
+static bool use_coop(const grid_handle *h, int alg, int K, const float *d_qdd, const float *d_Minv) {
+    if (!coop_available(alg) || d_qdd != nullptr || d_Minv != nullptr || h->coop[alg] == 1) return false;
+    if (h->coop[alg] == 2) return true;
+    if (h->split[alg] != 0 || h->pipeline[alg] == 2) return false;          // an explicit choice of another variant wins
+    const int tiles = (K + G::GRID_WAVE_SIZE - 1) / G::GRID_WAVE_SIZE;
+    return tiles <= GRID_COOP_AUTO_MAX_TILES;
+}
+
 // Two-pass (workspace) variants: generated for robots whose gradient working set exceeds the register file.
 static int workspace_count(int alg) {
     return alg == GRID_ALG_FD_DU ? G::FD_DU_WORKSPACE_COUNT : (alg == GRID_ALG_ID_DU ? G::ID_DU_WORKSPACE_COUNT : 0);
@@ -242,7 +260,10 @@ static bool use_pipeline(const grid_handle *h, int alg, const float *d_qdd, cons
     return h->pipeline[alg] == 2;      // auto = single kernel: since the recomputing column schedule it is the faster one
                                        // (Atlas-30 K=65536: 372 vs 531 us dID, 561 vs 799 us dFD); the two-pass variant is opt-in
 }
-static int ensure_workspace(grid_handle *h, int alg, int K) {
+static int ensure_workspace(grid_handle *h, int alg, int K, hipStream_t s) {
+    // one workspace per handle: work queued on another stream may still be reading it
+    if (h->workspace_busy && h->workspace_stream != s) GRID_TRY(hipStreamSynchronize(h->workspace_stream), "workspace: stream hand-over");
+    h->workspace_stream = s; h->workspace_busy = true;
     const size_t need = (size_t)workspace_count(alg) * (size_t)((K + G::GRID_WAVE_SIZE - 1) / G::GRID_WAVE_SIZE) * G::GRID_WAVE_SIZE * sizeof(T);
     if (need <= h->workspace_bytes) return 0;
     if (h->d_workspace != nullptr) { GRID_TRY(hipDeviceSynchronize(), "workspace: sync"); GRID_TRY(hipFree(h->d_workspace), "workspace: free"); h->d_workspace = nullptr; h->workspace_bytes = 0; }
@@ -255,8 +276,12 @@ static int launch_alg(grid_handle *h, int alg, float *d_out, const float *d_in, 
                       int K, float gravity, int blocks, int threads, hipStream_t s) {
     dim3 b, t;
     launch_shape(K, blocks, threads, &b, &t);
+    if (use_coop(h, alg, K, d_qdd, d_Minv)) {
+        G::forward_dynamics_gradient_coop_launch<T>(d_out, d_in, stride, h->d_robotModel, gravity, K, blocks > 0 ? blocks : 0, s);
+        return grid_check("kernel launch (tile-cooperative)");
+    }
     if (use_pipeline(h, alg, d_qdd, d_Minv)) {
-        if (int rc = ensure_workspace(h, alg, K)) return rc;
+        if (int rc = ensure_workspace(h, alg, K, s)) return rc;
         if (alg == GRID_ALG_FD_DU) G::forward_dynamics_gradient_pipeline_launch<T>(d_out, d_in, stride, nullptr, h->d_workspace, h->d_robotModel, gravity, K, b, t, s);
         else                       G::inverse_dynamics_gradient_pipeline_launch<T>(d_out, d_in, stride, d_qdd, h->d_workspace, h->d_robotModel, gravity, K, b, t, s);
         hipError_t e = hipGetLastError();
@@ -345,6 +370,17 @@ int grid_forward_dynamics_gradient_device(grid_handle *h, float *d_df_du, const 
     return launch_alg(h, GRID_ALG_FD_DU, d_df_du, d_q_qd_u, stride_q_qd_u, d_qdd, d_Minv, K, gravity, blocks, threads, pick_stream(h, stream));
 }
 
+int grid_rollout_row_count(void) { return G::ROLLOUT_ROW_COUNT; }
+int grid_forward_dynamics_gradient_rollout_device(grid_handle *h, float *d_traj, const float *d_x0, const float *d_u_traj,
+                                                  int K, int num_steps, float dt, float gravity, int blocks, int threads, void *stream) {
+    if (int rc = dev_prep(h, d_traj, d_x0, K, "grid_forward_dynamics_gradient_rollout_device")) return rc;
+    if (d_u_traj == nullptr || num_steps <= 0) { g_last_error = "grid_forward_dynamics_gradient_rollout_device: bad arguments"; return -1; }
+    dim3 b, t;
+    launch_shape(K, blocks, threads, &b, &t);
+    G::forward_dynamics_gradient_rollout_launch<T>(d_traj, d_x0, d_u_traj, dt, h->d_robotModel, gravity, K, num_steps, b, t, pick_stream(h, stream));
+    return grid_check("grid_forward_dynamics_gradient_rollout_device");
+}
+
 int grid_splits(int alg, int *out, int count) {
     const int *list; const int n = available_splits(alg, &list);
     for (int i = 0; i < n && i < count && out != nullptr; i++) out[i] = list[i];
@@ -364,6 +400,26 @@ int grid_set_split(grid_handle *h, int alg, int split) {
 int grid_get_split(grid_handle *h, int alg, int num_timesteps) {
     if (h == nullptr || alg < 0 || alg > 4) return -1;
     return effective_split(h, alg, num_timesteps);
+}
+
+int grid_coop_available(int alg) { return coop_available(alg) ? 1 : 0; }
+int grid_set_coop(grid_handle *h, int alg, int mode) {
+    if (h == nullptr || alg < 0 || alg > 4 || mode < 0 || mode > 2) { g_last_error = "grid_set_coop: bad arguments"; return -1; }
+    if (mode == 2 && !coop_available(alg)) { g_last_error = "grid_set_coop: no tile-cooperative kernel was generated for this robot/algorithm"; return -1; }
+    h->coop[alg] = mode;
+    return 0;
+}
+int grid_get_coop(grid_handle *h, int alg, int num_timesteps) {
+    if (h == nullptr || alg < 0 || alg > 4) return -1;
+    return use_coop(h, alg, num_timesteps, nullptr, nullptr) ? 1 : 0;
+}
+int grid_kernel_attributes_coop(int alg, int *out) {
+    if (out == nullptr || !coop_available(alg)) { g_last_error = "grid_kernel_attributes_coop: not available"; return -1; }
+    hipFuncAttributes a;
+    G::forward_dynamics_gradient_coop_attributes<T>(&a);
+    if (int rc = grid_check("grid_kernel_attributes_coop")) return rc;
+    out[0] = a.numRegs; out[1] = (int)a.sharedSizeBytes; out[2] = (int)a.localSizeBytes; out[3] = a.maxThreadsPerBlock;
+    return 0;
 }
 
 int grid_workspace_count(int alg) { return workspace_count(alg); }
@@ -388,16 +444,17 @@ int grid_time_device(grid_handle *h, int alg, float *d_out, const float *d_in, i
     hipStream_t s = pick_stream(h, stream);
     hipEvent_t e0, e1;
     GRID_TRY(hipEventCreate(&e0), "grid_time_device: event");
-    GRID_TRY(hipEventCreate(&e1), "grid_time_device: event");
-    GRID_TRY(hipEventRecord(e0, s), "grid_time_device: record");
-    for (int r = 0; r < reps; r++) {
-        if (int rc = launch_alg(h, alg, d_out, d_in, stride, d_qdd, d_Minv, K, gravity, blocks, threads, s)) return rc;
-    }
-    GRID_TRY(hipEventRecord(e1, s), "grid_time_device: record");
-    GRID_TRY(hipEventSynchronize(e1), "grid_time_device: sync");
+    { hipError_t ec = hipEventCreate(&e1); if (ec != hipSuccess) { (void)hipEventDestroy(e0); gpuAssert(ec, __FILE__, __LINE__); return grid_fail("grid_time_device: event"); } }
+    int rc = 0;
     float ms = 0.f;
-    GRID_TRY(hipEventElapsedTime(&ms, e0, e1), "grid_time_device: elapsed");
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    hipError_t e = hipEventRecord(e0, s);
+    for (int r = 0; r < reps && e == hipSuccess && rc == 0; r++) rc = launch_alg(h, alg, d_out, d_in, stride, d_qdd, d_Minv, K, gravity, blocks, threads, s);
+    if (e == hipSuccess && rc == 0) e = hipEventRecord(e1, s);
+    if (e == hipSuccess && rc == 0) e = hipEventSynchronize(e1);
+    if (e == hipSuccess && rc == 0) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);      // on every exit path
+    if (rc != 0) return rc;
+    if (e != hipSuccess) { gpuAssert(e, __FILE__, __LINE__); return grid_fail("grid_time_device"); }
     *ms_per_launch = ms / reps;
     return 0;
 }
@@ -419,6 +476,19 @@ int grid_kernel_attributes(int alg, int variant, int *out) {
     }
     hipFuncAttributes a;
     GRID_TRY(hipFuncGetAttributes(&a, fn), "grid_kernel_attributes");
+    out[0] = a.numRegs; out[1] = (int)a.sharedSizeBytes; out[2] = (int)a.localSizeBytes; out[3] = a.maxThreadsPerBlock;
+    return 0;
+}
+
+int grid_kernel_attributes_split(int alg, int split, int *out) {
+    if (out == nullptr) { g_last_error = "grid_kernel_attributes_split: out is NULL"; return -1; }
+    if (split <= 1) return grid_kernel_attributes(alg, 0, out);
+    hipFuncAttributes a;
+    bool ok = false;
+    if (alg == GRID_ALG_FD_DU) ok = G::forward_dynamics_gradient_split_attributes<T>(split, &a);
+    else if (alg == GRID_ALG_ID_DU) ok = G::inverse_dynamics_gradient_split_attributes<T>(split, &a);
+    if (!ok) { g_last_error = "grid_kernel_attributes_split: this split was not generated for this robot/algorithm"; return -1; }
+    if (int rc = grid_check("grid_kernel_attributes_split")) return rc;
     out[0] = a.numRegs; out[1] = (int)a.sharedSizeBytes; out[2] = (int)a.localSizeBytes; out[3] = a.maxThreadsPerBlock;
     return 0;
 }

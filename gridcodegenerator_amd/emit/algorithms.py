@@ -156,6 +156,11 @@ def rnea(tr, spec, X, I, qd, qdd, gravity):
 # ------------------------------------------------------------------------------------------------
 def direct_minv(tr, spec, X, I):
     """Upper-triangular Minv[j][k] (k >= j) as traced scalars; entries k < j are None."""
+    with tr.mixed_region():
+        return _direct_minv(tr, spec, X, I)
+
+
+def _direct_minv(tr, spec, X, I):
     n = spec.n
     IA = [[[I[j][r][c] if r <= c else None for c in range(6)] for r in range(6)] for j in range(n)]
     for j in range(n):  # mirror so IA[r][c] is IA[c][r] (symmetric by construction)
@@ -237,8 +242,15 @@ def minv_sym(Minv, r, c):
 def fd_finish(tr, spec, Minv, u, c):
     """qdd = Minv_sym (u - c)  (algorithms/_forward_dynamics.py:21-49)."""
     n = spec.n
-    umc = [u[k] - c[k] for k in range(n)]
-    return [tr.dot([(minv_sym(Minv, r, k), umc[k]) for k in range(n)]) for r in range(n)]
+    with tr.mixed_region():
+        umc = [u[k] - c[k] for k in range(n)]
+        qdd = [tr.dot([(minv_sym(Minv, r, k), umc[k]) for k in range(n)]) for r in range(n)]
+    return [tr.cast(x, 0) if tr.mixed else x for x in qdd]      # everything downstream (RNEA at qdd, the gradient) is in C
+
+
+def minv_in_compute_type(tr, Minv):
+    """Minv entries converted once to the compute type C (mixed precision: the recursion ran in D)."""
+    return [[tr.cast(e, 0) if (e is not None and tr.mixed) else e for e in row] for row in Minv]
 
 
 # ------------------------------------------------------------------------------------------------
@@ -308,9 +320,33 @@ def rnea_grad(tr, spec, X, I, qd, v, a, f, gravity):
     return dc
 
 
+def sym_minv_times_columns(tr, spec, entry, dc_lo, dc_hi):
+    """-Minv_sym @ [dc_lo | dc_hi] for ONE gradient column with every upper-triangle entry of Minv fetched once:
+    entry(r, k) (r <= k) -> traced value or None (structural zero); dc_lo / dc_hi: {row: value} of the non-zero rows.
+    4 multiply-adds per fetched entry (both halves, both triangles) -- for cores that re-read Minv from LDS per column."""
+    n = spec.n
+    acc_lo = [tr.zero() for _ in range(n)]
+    acc_hi = [tr.zero() for _ in range(n)]
+    for k in range(n):
+        for r in range(k + 1):
+            need_rk = k in dc_lo             # contributes to row r through dc[k]
+            need_kr = (r != k) and (r in dc_lo)
+            if not (need_rk or need_kr):
+                continue
+            m = entry(r, k)
+            if m is None:
+                continue
+            if need_rk:
+                acc_lo[r] = tr.fma(m, dc_lo[k], acc_lo[r]); acc_hi[r] = tr.fma(m, dc_hi[k], acc_hi[r])
+            if need_kr:
+                acc_lo[k] = tr.fma(m, dc_lo[r], acc_lo[k]); acc_hi[k] = tr.fma(m, dc_hi[r], acc_hi[k])
+    return [-x for x in acc_lo], [-x for x in acc_hi]
+
+
 def fd_grad_finish(tr, spec, Minv, dc, cols=None):
     """df_du = -Minv_sym [dc_dq | dc_dqd]  (algorithms/_forward_dynamics_gradient.py:48-57) on pairs; only `cols` if given."""
     n = spec.n
+    Minv = minv_in_compute_type(tr, Minv)
     out = [[None] * n for _ in range(n)]
     for col in (range(n) if cols is None else cols):
         for r in range(n):

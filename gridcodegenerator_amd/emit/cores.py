@@ -135,6 +135,145 @@ def core_forward_dynamics_gradient(spec, use_qdd_minv, cols=None):
     return tr
 
 
+class CoopSlots:
+    """Exchange-region slots of the tile-cooperative forward-dynamics-gradient kernels: the structurally non-zero upper
+    triangle of Minv, then the bias torques c / the accelerations qdd (same slots, used one after the other).  Value `slot` of
+    lane l lives at slot*64 + l of the block's LDS region."""
+
+    def __init__(self, spec):
+        n = spec.n
+        nz = alg.minv_zero_pattern(spec)
+        self.minv = {}
+        for r in range(n):
+            for k in range(r, n):
+                if nz[r][k]:
+                    self.minv[(r, k)] = len(self.minv)
+        self.c = [len(self.minv) + j for j in range(n)]
+        self.qdd = list(self.c)         # c is read only by the producer, before it publishes qdd: the slots are shared
+        self.count = len(self.minv) + n
+
+    def entry(self, tr, r, k):
+        """Minv_sym[r][k] as a fresh exchange read (None: structural zero)."""
+        slot = self.minv.get((r, k) if r <= k else (k, r))
+        return tr.xch_get(slot) if slot is not None else None
+
+
+COOP_ROLES = ("producer", "consumer_c", "consumer")
+
+
+def _coop_prologue(tr, spec, slots, role, X, I, qd, u, g):
+    """Phases 1 and 2 of a tile-cooperative core; returns qdd (read from the exchange region by every wave).
+
+    producer:  Minv (in double when the build is mixed-precision) -> exchange region | barrier | c from the exchange region,
+               qdd = Minv (u - c) from the Minv it still holds in registers (so the cond(M)-amplified product sees the
+               unrounded Minv) -> exchange region | barrier
+    consumers: RNEA at qdd = 0 while the producer is busy; one of them publishes c | barrier | barrier"""
+    n = spec.n
+    if role == "producer":
+        Minv = alg.direct_minv(tr, spec, X, I)
+        for (r, k), slot in slots.minv.items():
+            tr.xch_put(slot, Minv[r][k])
+        tr.barrier()
+        c = [tr.xch_get(slots.c[j]) for j in range(n)]
+        qdd = alg.fd_finish(tr, spec, Minv, u, c)
+        for j in range(n):
+            tr.xch_put(slots.qdd[j], qdd[j])
+        tr.barrier()
+    else:
+        c = alg.rnea(tr, spec, X, I, qd, None, g)[0]
+        for j in range(n):
+            if role == "consumer_c":
+                tr.xch_put(slots.c[j], c[j])
+            else:
+                tr.anchor(c[j])
+        tr.barrier()
+        tr.barrier()
+    return [tr.xch_get(slots.qdd[j]) for j in range(n)]
+
+
+def core_forward_dynamics_gradient_coop(spec, role, cols, slots):
+    """Fused forward-dynamics-gradient core of ONE wave of a tile-cooperative block (small robots).  The block's waves share
+    the prefix instead of repeating it (column-split kernels): one wave computes Minv while the others compute the bias
+    torques, results cross through LDS, then every wave finishes qdd = Minv (u - c) and its own group of gradient columns.
+    Same arithmetic, in the same order, as core_forward_dynamics_gradient (bit-identical results in fp32)."""
+    assert role in COOP_ROLES
+    n = spec.n
+    tr, ins, g, X, I = _setup(spec, ["q", "qd", "u"])
+    qdd = _coop_prologue(tr, spec, slots, role, X, I, ins["qd"], ins["u"], g)
+    Mx = {}
+    for (r, k), slot in slots.minv.items():
+        Mx[(r, k)] = tr.xch_get(slot)
+    Minv = [[(Mx.get((r, k), tr.zero()) if r <= k else None) for k in range(n)] for r in range(n)]
+    c2, v, a, f = alg.rnea(tr, spec, X, I, ins["qd"], qdd, g)
+    dc = alg.rnea_grad(tr, spec, X, I, ins["qd"], v, a, f, g)
+    out = alg.fd_grad_finish(tr, spec, Minv, dc, cols)
+    _out_grad(tr, spec, out, cols)
+    return tr
+
+
+def rollout_row_count(spec):
+    """Values per configuration and step of the rollout output: [x+ (2n) | A (2n x 2n, column-major) | B (2n x n)]."""
+    return 2 * spec.n * (1 + 3 * spec.n)
+
+
+class RolloutChunks:
+    """Bookkeeping of the rollout step cores: the output row is written in chunks of 2n values (x+, then one column of A or
+    B each); a core may emit the chunks in any order -- chunk k of the emission goes to row offset bases[k]."""
+
+    def __init__(self, tr, n):
+        self.tr, self.n, self.bases = tr, n, []
+
+    def put(self, base, values):
+        assert len(values) == 2 * self.n
+        k = len(self.bases)
+        self.bases.append(base)
+        for i, v in enumerate(values):
+            self.tr.out(2 * self.n * k + i, v)
+
+    def x_next(self, q, qd, qdd, dt):
+        n = self.n
+        qdn = [qd[j] + dt * qdd[j] for j in range(n)]               # semi-implicit Euler: velocity first,
+        qn = [q[j] + dt * qdn[j] for j in range(n)]                 # then the position with the NEW velocity
+        self.put(0, qn + qdn)
+
+    def B_columns(self, Minv, dt, dt2):
+        n = self.n
+        for c in range(n):
+            col = [alg.minv_sym(Minv, r, c) for r in range(n)]
+            self.put(2 * n + 4 * n * n + 2 * n * c, [dt2 * e for e in col] + [dt * e for e in col])
+
+    def A_columns(self, col, lo, hi, dt, dt2):
+        """lo = dqdd/dq[:, col], hi = dqdd/dqd[:, col] -> columns col and n + col of A."""
+        n = self.n
+        one = lambda r: 1.0 if r == col else 0.0
+        self.put(2 * n + 2 * n * col, [dt2 * lo[r] + one(r) for r in range(n)] + [dt * lo[r] for r in range(n)])
+        self.put(2 * n + 2 * n * (n + col), [dt2 * hi[r] + dt * one(r) for r in range(n)] + [dt * hi[r] + one(r) for r in range(n)])
+
+
+def core_rollout_step(spec):
+    """One semi-implicit Euler step of the forward dynamics with its linearisation (fused trace, small robots):
+    in: q, qd, u, dt -> out row [x+ | A | B] (oracle/rbd_oracle.py: rollout_step).  Returns (tracer, chunk bases)."""
+    n = spec.n
+    tr, ins, g, X, I = _setup(spec, ["q", "qd", "u"])
+    dt = tr.inp("in.dt()")
+    dt2 = dt * dt
+    Minv = alg.direct_minv(tr, spec, X, I)
+    c, v, a, f = alg.rnea(tr, spec, X, I, ins["qd"], None, g)
+    qdd = alg.fd_finish(tr, spec, Minv, ins["u"], c)
+    c, v, a, f = alg.rnea(tr, spec, X, I, ins["qd"], qdd, g)
+    dc = alg.rnea_grad(tr, spec, X, I, ins["qd"], v, a, f, g)
+    df = alg.fd_grad_finish(tr, spec, Minv, dc)
+    Minv32 = alg.minv_in_compute_type(tr, Minv)
+    ch = RolloutChunks(tr, n)
+    ch.x_next(ins["q"], ins["qd"], qdd, dt)
+    for col in range(n):
+        ch.A_columns(col, [df[r][col].lo for r in range(n)], [df[r][col].hi for r in range(n)], dt, dt2)
+    ch.B_columns(Minv32, dt, dt2)
+    order = sorted(range(len(ch.bases)), key=lambda k: ch.bases[k])
+    assert [ch.bases[k] for k in order] == [2 * n * k for k in range(1 + 3 * n)]
+    return tr, list(ch.bases)
+
+
 def _arith_ops(tr):
     return tr.arith_instructions()
 
@@ -343,6 +482,42 @@ def inner_forward_dynamics(spec):
     return tr
 
 
+def inner_inverse_dynamics_gradient_columns(spec):
+    """inverse_dynamics_gradient_inner for large robots: the column-serial walk of rnea_grad_columns over s_vaf (v, a, f are
+    re-read per column, X_j(q) is rematerialised per column from the lane's sin/cos table), creation-order emission.  The
+    fused trace below keeps ~900 values alive for a 30-joint robot and its GPU build spilled kilobytes per lane."""
+    n = spec.n
+    tr = Tracer()
+    q = [tr.inp("s_q[%d]" % j) for j in range(n)]
+    qd = [tr.inp("s_qd[%d]" % j) for j in range(n)]
+    g = tr.inp("gravity")
+    trig = [(tr.inp("s_XImats[%d]" % j), tr.inp("s_XImats[%d]" % (n + j))) if spec.uses_trig[j] else None for j in range(n)]
+    I = alg.build_I(tr, spec)
+    serial = [0]
+
+    def load6(base, j):
+        serial[0] += 1
+        return [tr.inp("s_vaf[%d]/*%d*/" % (base + 6 * j + r, serial[0])) for r in range(6)]
+
+    def loader(kind, j):
+        if kind == "v":
+            return load6(0, j)
+        if kind == "f":
+            return load6(12 * n, j)
+        Xj = alg.build_X_joint(tr, spec, j, q[j], trig[j])          # "xa": X_j a_parent (base: X_j[:, 5] g)
+        p = spec.parent[j]
+        return alg.matvec(tr, Xj, load6(6 * n, p)) if p != -1 else [Xj[r][5] * g for r in range(6)]
+
+    def emit_column(col, dc):
+        for half in (0, 1):
+            for r in range(n):
+                e = dc.get(r)
+                tr.out("s_dc_du[%d]" % (half * n * n + n * col + r), e[half] if e is not None else tr.zero())
+
+    alg.rnea_grad_columns(tr, spec, I, q, qd, trig, loader, emit_column, prefetch=0)
+    return tr
+
+
 def inner_inverse_dynamics_gradient(spec):
     """inverse_dynamics_gradient_inner: v, a, f come in through s_vaf (as in the reference)."""
     tr, ins, g, X, I = _setup(spec, ["q", "qd"], "inner")
@@ -482,7 +657,8 @@ def recompute_table_size(spec, kind, use_qdd=False, use_qdd_minv=False):
     return spec.n * (3 + (1 if has_qdd else 0) + (1 if any(not t for t in spec.uses_trig) else 0))
 
 
-def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table=False, facc_separate=True, cols=None):
+def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table=False, facc_separate=True, cols=None, rollout=None,
+                            coop=None):
     """Column-serial gradient core that keeps almost nothing alive between columns: inside each column the velocities,
     accelerations and accumulated forces it needs (path root -> column joint, and the column's subtree) are RECOMPUTED
     from q, qd, qdd instead of being held in registers (the fused demand-ordered trace keeps 880-1160 values alive for
@@ -490,6 +666,14 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
 
     kind "id": dc_du at (q, qd[, qdd]).  kind "fd": df_du; Minv and qdd are computed first (default) or read from the
     inputs (use_qdd_minv: the reference's USE_QDD_MINV_FLAG variant; Minv entries are read where they are used).
+
+    coop = (role, CoopSlots): the core of one wave of a tile-cooperative block (kind "fd"): Minv is produced by one wave and
+    read from the block's LDS exchange region where it is used (never held in registers: the 465 values of Atlas-30 are what
+    made every dFD column group spill), see core_forward_dynamics_gradient_coop.
+
+    rollout: a list that receives the chunk bases -- the core then is one semi-implicit Euler step with its linearisation
+    (kind "fd" only; see core_rollout_step): x+ and the B columns are emitted after the prologue, two A columns per gradient
+    column.
 
     table=True: sin q, cos q, qd, qdd are parked in a lane-private table after the prologue (tab_put) and re-loaded per
     column (tab_get) instead of staying in ~4n registers for the whole kernel: with them resident the Atlas-30 kernels
@@ -504,7 +688,16 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
     trig = alg.trig_from_q(tr, spec, q)
     I = alg.build_I(tr, spec)
     Minv = None
-    if kind == "fd" and not use_qdd_minv:
+    if coop is not None:
+        assert kind == "fd" and not use_qdd_minv and not table and rollout is None
+        role, slots = coop
+        mark = tr.cse_mark()
+        u = [tr.inp("in.u(%d)" % j) for j in range(n)]
+        X = alg.build_X(tr, spec, q, trig)
+        qdd = list(_coop_prologue(tr, spec, slots, role, X, I, qd, u, g))
+        tr.fence()
+        tr.cse_release(mark, keep=[t.ref for pair in trig if pair is not None for t in pair])
+    elif kind == "fd" and not use_qdd_minv:
         mark = tr.cse_mark()
         u = [tr.inp("in.u(%d)" % j) for j in range(n)]
         X = alg.build_X(tr, spec, q, trig)
@@ -512,6 +705,14 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
         c = alg.rnea(tr, spec, X, I, qd, None, g)[0]
         qdd = alg.fd_finish(tr, spec, Minv, u, c)
         qdd = list(qdd)
+        Minv = alg.minv_in_compute_type(tr, Minv)      # mixed precision: only the rounded copies stay alive below
+        if rollout is not None:
+            dt = tr.inp("in.dt()")
+            dt2 = dt * dt
+            chunks = RolloutChunks(tr, n)
+            chunks.bases = rollout                     # (the caller's list)
+            chunks.x_next(q, qd, qdd, dt)
+            chunks.B_columns(Minv, dt, dt2)
         tr.fence()
         tr.cse_release(mark, keep=[t.ref for pair in trig if pair is not None for t in pair])
     elif kind == "fd" or use_qdd:
@@ -632,6 +833,8 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
         a, b = (r, k) if r <= k else (k, r)
         if not nz[a][b]:
             return None
+        if coop is not None:
+            return coop[1].entry(tr, a, b)
         return Minv[a][b] if Minv is not None else tr.inp("in.Minv(%d)" % (n * b + a))
 
     # cols = [c0..c1] (column-split kernels): only those columns, written at LOCAL indices -- d/dq columns at n*(col-c0),
@@ -648,15 +851,33 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
                     e = dc.get(r)
                     tr.out(half * hi_off + lo_base(col) + r, e[half] if e is not None else tr.zero())
             return
+        if coop is not None:
+            # every upper-triangle entry fetched once per column from the exchange region (4 multiply-adds per LDS read)
+            lo, hi = alg.sym_minv_times_columns(tr, spec, lambda r, k: minv_entry(r, k),
+                                                {k: dc[k][0] for k in rows}, {k: dc[k][1] for k in rows})
+            for r in range(n):
+                tr.out(lo_base(col) + r, lo[r])
+            for r in range(n):
+                tr.out(hi_off + lo_base(col) + r, hi[r])
+            return
         hi = []
+        lo = []
         for r in range(n):
             m = [(k, minv_entry(r, k)) for k in rows]
             m = [(k, e) for (k, e) in m if e is not None]
-            tr.out(lo_base(col) + r, -tr.dot([(e, dc[k][0]) for (k, e) in m]))
+            lo.append(-tr.dot([(e, dc[k][0]) for (k, e) in m]))
+            if rollout is None:
+                tr.out(lo_base(col) + r, lo[-1])
             hi.append(-tr.dot([(e, dc[k][1]) for (k, e) in m]))
+        if rollout is not None:
+            chunks.A_columns(col, lo, hi, dt, dt2)
+            return
         for r in range(n):
             tr.out(hi_off + lo_base(col) + r, hi[r])
 
     keep = ([t.ref for row in Minv for t in row if t is not None] if Minv is not None else [])
+    if rollout is not None:
+        assert kind == "fd" and not use_qdd_minv and cols is None and not table
+        keep = keep + [dt.ref, dt2.ref]
     alg.rnea_grad_columns(tr, spec, I, q, qd, trig, loader, emit_column, order=cols, prefetch=0, xof=Xof, keep=keep)
     return tr

@@ -113,6 +113,8 @@ class P:
 class Tracer:
     def __init__(self):
         self.nodes = [None]      # 1-based; each node: (op, a, b, c) with operand refs / payload
+        self.ntype = [0]         # per node: 0 = compute type C (float), 1 = high-precision type D (double)
+        self.hp = False          # arithmetic created while True is typed D (mixed precision, see high())
         self.cse = {}
         self.outputs = []        # (dst_expr, ref)
         self.out_pos = []        # node count when each output was recorded
@@ -130,13 +132,70 @@ class Tracer:
         """Load of an input element (a C expression such as ``s_q[3]``)."""
         return V(self, self._node(("in", expr, None, None)))
 
+    def _type_of_new(self, key):
+        op = key[0]
+        if op == "in":
+            return 0                                  # inputs arrive in the storage type
+        if op in ("lnd", "lo", "hi"):
+            return self.ntype[key[1]]                 # same value, same type
+        if op == "cvt":
+            return key[2]                             # explicit conversion to C (0) or D (1)
+        return 1 if self.hp else 0
+
     def _node(self, key):
-        idx = self.cse.get(key)
+        ty = self._type_of_new(key)
+        idx = self.cse.get((key, ty))
         if idx is None:
             self.nodes.append(key)
+            self.ntype.append(ty)
             idx = len(self.nodes) - 1
-            self.cse[key] = idx
+            self.cse[(key, ty)] = idx
         return idx
+
+    def high(self):
+        """Context manager: arithmetic traced inside is carried out in the high-precision type D (double).  Operands of
+        the other type are converted at the use (widening is exact; narrowing rounds once)."""
+        tr = self
+
+        class _High:
+            def __enter__(self_inner):
+                self_inner.prev = tr.hp
+                tr.hp = True
+
+            def __exit__(self_inner, *exc):
+                tr.hp = self_inner.prev
+        return _High()
+
+    mixed = False           # class-wide switch (GRiDCodeGenerator(precision="mixed") sets it for a build)
+
+    def mixed_region(self):
+        """high() when the build is mixed-precision, otherwise a no-op: wraps the cond(M)-amplified parts of the forward
+        dynamics (the Minv recursion and qdd = Minv (u - c)), see DESIGN.md section 4."""
+        if self.mixed:
+            return self.high()
+        import contextlib
+        return contextlib.nullcontext()
+
+    def cast(self, a, hp):
+        """The same value converted ONCE to the compute type C (hp = 0, rounds) or D (hp = 1, exact): a node of its own, so
+        every later use shares the conversion and the original may die."""
+        if isinstance(a.ref, float) or self.ntype[abs(a.ref)] == hp:
+            return a
+        sign = 1 if a.ref > 0 else -1
+        return V(self, sign * self._node(("cvt", abs(a.ref), hp, None)))
+
+    def low(self):
+        """Context manager: the opposite of high() (compute type C inside)."""
+        tr = self
+
+        class _Low:
+            def __enter__(self_inner):
+                self_inner.prev = tr.hp
+                tr.hp = False
+
+            def __exit__(self_inner, *exc):
+                tr.hp = self_inner.prev
+        return _Low()
 
     def comment(self, text):
         self.comments.setdefault(len(self.nodes), []).append(text)
@@ -244,7 +303,7 @@ class Tracer:
         # withdraw the two scalar nodes (they are the last two appended) and emit one packed node instead
         for _ in range(2):
             key = self.nodes.pop()
-            del self.cse[key]
+            del self.cse[(key, self.ntype.pop())]
         if kind == "fma":
             key = ("pkfma", (aL.ref, aH.ref), (bL.ref, bH.ref), (cL.ref, cH.ref))
         elif kind == "mul":
@@ -341,6 +400,25 @@ class Tracer:
         self._tab_serial = getattr(self, "_tab_serial", 0) + 1
         return self.inp("in.tab_get(%d)/*%d*/" % (slot, self._tab_serial))
 
+    # --- tile-cooperative kernels: the waves of a block exchange per-configuration values through LDS ---------------------
+    def xch_put(self, slot, val):
+        """Publish a value to the block's exchange region (LDS): read by the same lane index of the OTHER waves of the block
+        after the barrier."""
+        self.out("xch:%d" % slot, val)
+
+    def xch_get(self, slot):
+        """Read a published value: a fresh load per request (short live range, like tab_get)."""
+        self._xch_serial = getattr(self, "_xch_serial", 0) + 1
+        return self.inp("in.xch_get(%d)/*%d*/" % (slot, self._xch_serial))
+
+    def barrier(self):
+        """Block barrier at this point of the core (every wave of the block executes exactly the same number of them)."""
+        self.out("barrier", 0.0)
+
+    def anchor(self, val):
+        """Force `val` to be computed before this point (work that should overlap with another wave's producer phase)."""
+        self.out("anchor", val)
+
     def launder(self, a):
         """Same value, but opaque to the compiler from here on (an empty asm with the register as in/out operand): a later
         expression over the laundered value is NOT a common subexpression of the same expression over the original, so
@@ -364,15 +442,15 @@ class Tracer:
         This is how the explicit schedules rematerialise X_j(q) entries and reload workspace values per column."""
         keep = set(abs(r) for r in keep if not isinstance(r, float))
         for k in range(mark, len(self.nodes)):
-            if k not in keep and self.cse.get(self.nodes[k]) == k:
-                del self.cse[self.nodes[k]]
+            if k not in keep and self.cse.get((self.nodes[k], self.ntype[k])) == k:
+                del self.cse[(self.nodes[k], self.ntype[k])]
 
     # --- analysis / emission ---------------------------------------------------------------------
     def _deps(self, k):
         op, a, b, c = self.nodes[k]
         if op == "in":
             return ()
-        if op in ("lo", "hi", "lnd"):
+        if op in ("lo", "hi", "lnd", "cvt"):
             return (a,)
         if op.startswith("pk"):
             return tuple(abs(r) for pair in (a, b, c) if pair is not None for r in pair if not isinstance(r, float))
@@ -396,33 +474,38 @@ class Tracer:
         counts = {}
         for k in range(1, len(self.nodes)):
             if live[k]:
-                counts[self.nodes[k][0]] = counts.get(self.nodes[k][0], 0) + 1
+                name = self.nodes[k][0] + (".d" if self.ntype[k] else "")      # ".d": carried out in double
+                counts[name] = counts.get(name, 0) + 1
         return counts
 
     def flops(self):
         c = self.op_counts()
-        return (2 * c.get("fma", 0) + c.get("mul", 0) + c.get("add", 0)
+        return (2 * (c.get("fma", 0) + c.get("fma.d", 0)) + c.get("mul", 0) + c.get("add", 0) + c.get("mul.d", 0) + c.get("add.d", 0)
                 + 4 * c.get("pkfma", 0) + 2 * c.get("pkmul", 0) + 2 * c.get("pkadd", 0))
 
     def arith_instructions(self):
         """Arithmetic instructions one lane issues (a packed op is one instruction)."""
         c = self.op_counts()
-        return sum(c.get(k, 0) for k in ("fma", "mul", "add", "pkfma", "pkmul", "pkadd"))
+        return sum(c.get(k, 0) for k in ("fma", "mul", "add", "fma.d", "mul.d", "add.d", "pkfma", "pkmul", "pkadd"))
 
     @staticmethod
-    def _lit(x):
+    def _lit(x, hp=0):
+        ty = "D" if hp else "C"
         if x == int(x) and abs(x) < 1e9:
-            return "(C)%d" % int(x)
-        return "(C)%s" % repr(float(x))
+            return "(%s)%d" % (ty, int(x))
+        return "(%s)%s" % (ty, repr(float(x)))
 
-    def _opnd(self, r):
+    def _opnd(self, r, hp=0):
+        """Operand text in the type of the consuming operation (hp: D, else C); converts where the node's type differs."""
         if isinstance(r, float):
-            return self._lit(r)
+            return self._lit(r, hp)
         op = self.nodes[abs(r)][0]
         if op in ("lo", "hi"):
             name = "t%d.%s" % (self.nodes[abs(r)][1], "x" if op == "lo" else "y")
         else:
             name = "t%d" % abs(r)
+        if self.ntype[abs(r)] != hp:
+            name = "(%s)%s" % ("D" if hp else "C", name)
         return name if r > 0 else "-" + name
 
     def _pair_opnd(self, pair):
@@ -450,13 +533,16 @@ class Tracer:
         trig_args = {}
         for k in range(1, len(self.nodes)):
             if live[k] and self.nodes[k][0] in ("sin", "cos"):
-                trig_args.setdefault(self.nodes[k][1], {})[self.nodes[k][0]] = k
+                trig_args.setdefault((self.nodes[k][1], self.ntype[k]), {})[self.nodes[k][0]] = k
         emitted = [False] * len(self.nodes)
         lines = []
         count = [0]
 
         def emit_node(k):
             op, a, b, c = self.nodes[k]
+            hp = self.ntype[k]
+            ty = "D" if hp else "C"
+            o = lambda r: self._opnd(r, hp)
             emitted[k] = True
             count[0] += 1
             if fence_every and count[0] % fence_every == 0:
@@ -464,23 +550,25 @@ class Tracer:
             if op == "in":
                 lines.append("%sconst C t%d = (C)%s;" % (indent, k, a))
             elif op == "mul":
-                lines.append("%sconst C t%d = %s * %s;" % (indent, k, self._opnd(a), self._opnd(b)))
+                lines.append("%sconst %s t%d = %s * %s;" % (indent, ty, k, o(a), o(b)))
             elif op == "add":
                 if not isinstance(b, float) and b < 0:
-                    lines.append("%sconst C t%d = %s - %s;" % (indent, k, self._opnd(a), self._opnd(-b)))
+                    lines.append("%sconst %s t%d = %s - %s;" % (indent, ty, k, o(a), o(-b)))
                 elif isinstance(b, float) and b < 0:
-                    lines.append("%sconst C t%d = %s - %s;" % (indent, k, self._opnd(a), self._lit(-b)))
+                    lines.append("%sconst %s t%d = %s - %s;" % (indent, ty, k, o(a), self._lit(-b, hp)))
                 else:
-                    lines.append("%sconst C t%d = %s + %s;" % (indent, k, self._opnd(a), self._opnd(b)))
+                    lines.append("%sconst %s t%d = %s + %s;" % (indent, ty, k, o(a), o(b)))
             elif op == "fma":
-                lines.append("%sconst C t%d = grid_fma(%s, %s, %s);" % (indent, k, self._opnd(a), self._opnd(b), self._opnd(c)))
+                lines.append("%sconst %s t%d = grid_fma(%s, %s, %s);" % (indent, ty, k, o(a), o(b), o(c)))
             elif op == "rcp":
-                lines.append("%sconst C t%d = (C)1 / %s;" % (indent, k, self._opnd(a)))
+                lines.append("%sconst %s t%d = grid_rcp(%s);" % (indent, ty, k, o(a)))
             elif op == "lnd":
                 count[0] -= 1       # no instruction when the source dies here (the usual case)
-                lines.append("%sC t%d = %s; GRID_LAUNDER(t%d);" % (indent, k, self._opnd(a), k))
+                lines.append("%s%s t%d = %s; GRID_LAUNDER(t%d);" % (indent, ty, k, o(a), k))
             elif op in ("lo", "hi"):
                 count[0] -= 1       # a register half of a packed value: no instruction
+            elif op == "cvt":
+                lines.append("%sconst %s t%d = (%s)t%d;" % (indent, ty, k, ty, a))
             elif op == "pkfma":
                 lines.append("%sconst C2 t%d = grid_pk_fma(%s, %s, %s);" % (indent, k, self._pair_opnd(a), self._pair_opnd(b), self._pair_opnd(c)))
             elif op == "pkmul":
@@ -488,14 +576,14 @@ class Tracer:
             elif op == "pkadd":
                 lines.append("%sconst C2 t%d = %s + %s;" % (indent, k, self._pair_opnd(a), self._pair_opnd(b)))
             elif op in ("sin", "cos"):
-                pair = trig_args[a]
+                pair = trig_args[(a, hp)]
                 if "sin" in pair and "cos" in pair:
                     emitted[pair["sin"]] = True
                     emitted[pair["cos"]] = True
-                    lines.append("%sC t%d, t%d; grid_sincos(%s, &t%d, &t%d);" % (
-                        indent, pair["sin"], pair["cos"], self._opnd(a), pair["sin"], pair["cos"]))
+                    lines.append("%s%s t%d, t%d; grid_sincos(%s, &t%d, &t%d);" % (
+                        indent, ty, pair["sin"], pair["cos"], o(a), pair["sin"], pair["cos"]))
                 else:
-                    lines.append("%sconst C t%d = grid_%s(%s);" % (indent, k, op, self._opnd(a)))
+                    lines.append("%sconst %s t%d = grid_%s(%s);" % (indent, ty, k, op, o(a)))
             else:
                 raise AssertionError(op)
 
@@ -513,7 +601,7 @@ class Tracer:
                         lines.append(indent + fence_stmt)
                         continue
                     dst, r = self.outputs[i]
-                    lines.append(indent + store(dst, self._opnd(r)))
+                    lines.append(indent + store(dst, self._opnd(r, self._store_type(r))))
                     if after_store is not None:
                         extra = after_store(i)
                         if extra:
@@ -535,12 +623,16 @@ class Tracer:
                     for d in reversed(deps(k)):
                         if not emitted[d]:
                             stack.append((d, False))
-            lines.append(indent + store(dst, self._opnd(r)))
+            lines.append(indent + store(dst, self._opnd(r, self._store_type(r))))
             if after_store is not None:
                 extra = after_store(i)
                 if extra:
                     lines.append(indent + extra)
         return lines
+
+    def _store_type(self, r):
+        """An output is converted to the storage type T once, from whatever type its node has."""
+        return 0 if isinstance(r, float) else self.ntype[abs(r)]
 
     def evaluate(self, inputs, dtype="float64"):
         """Interpret the live part of the trace with numpy (batched).  Used by the CPU-side tests to
@@ -554,35 +646,44 @@ class Tracer:
         dt = np.dtype(dtype)
         live = self.live_nodes()
         val = [None] * len(self.nodes)
+        f32 = (dt != np.float64)
 
-        def get(r):
+        def r32(x):
+            return np.asarray(x, dtype=np.float64).astype(np.float32).astype(np.float64)
+
+        def get(r, hp=0):
+            # operand as seen by an operation of type hp (0: C, 1: D); in float64 mode there is only one type
             if isinstance(r, float):
-                return np.float64(r) if dt == np.float64 else np.float64(np.float32(r))
+                return np.float64(r) if (hp or not f32) else np.float64(np.float32(r))
             x = val[abs(r)]
+            if f32 and not hp and self.ntype[abs(r)]:
+                x = r32(x)                       # narrowing conversion at the use
             return x if r > 0 else -x
-
-        def rnd(x):
-            return x if dt == np.float64 else x.astype(np.float32).astype(np.float64)
 
         for k in range(1, len(self.nodes)):
             if not live[k]:
                 continue
             op, a, b, c = self.nodes[k]
+            hp = self.ntype[k]
+            rnd = (lambda x: x) if (hp or not f32) else r32
+            g = lambda r: get(r, hp)
             if op == "in" and a.startswith("in.tab_get("):
                 slot = a[len("in.tab_get("):a.index(")")]
                 src = [r for (dst, r) in self.outputs if dst == "tab:" + slot]
                 assert len(src) == 1 and (isinstance(src[0], float) or abs(src[0]) < k), "table slot read before it was written"
-                val[k] = get(src[0]) + np.zeros(1)
+                val[k] = rnd(get(src[0]) + np.zeros(1))
+            elif op == "in" and a.startswith("in.xch_get("):
+                val[k] = rnd(np.asarray(inputs[a.split("/*")[0]], dtype=np.float64))       # published by another wave's core
             elif op == "in":
                 val[k] = rnd(np.asarray(inputs[a], dtype=np.float64))
             elif op == "mul":
-                val[k] = rnd(get(a) * get(b))
+                val[k] = rnd(g(a) * g(b))
             elif op == "add":
-                val[k] = rnd(get(a) + get(b))
+                val[k] = rnd(g(a) + g(b))
             elif op == "fma":
-                val[k] = rnd(get(a) * get(b) + get(c))
+                val[k] = rnd(g(a) * g(b) + g(c))
             elif op == "rcp":
-                val[k] = rnd(1.0 / get(a))
+                val[k] = rnd(1.0 / g(a))
             elif op == "pkfma":
                 val[k] = (rnd(get(a[0]) * get(b[0]) + get(c[0])), rnd(get(a[1]) * get(b[1]) + get(c[1])))
             elif op == "pkmul":
@@ -591,12 +692,21 @@ class Tracer:
                 val[k] = (rnd(get(a[0]) + get(b[0])), rnd(get(a[1]) + get(b[1])))
             elif op == "lnd":
                 val[k] = val[a]
+            elif op == "cvt":
+                val[k] = rnd(val[a])
             elif op == "lo":
                 val[k] = val[a][0]
             elif op == "hi":
                 val[k] = val[a][1]
             elif op == "sin":
-                val[k] = rnd(np.sin(get(a)))
+                val[k] = rnd(np.sin(g(a)))
             elif op == "cos":
-                val[k] = rnd(np.cos(get(a)))
-        return [get(r) if not isinstance(r, float) else np.float64(r) for (_, r) in self.outputs]
+                val[k] = rnd(np.cos(g(a)))
+        outs = []
+        for (_, r) in self.outputs:
+            if isinstance(r, float):
+                outs.append(np.float64(r))
+            else:
+                x = get(r, self.ntype[abs(r)])
+                outs.append(r32(x) if f32 else x)     # stored as T
+        return outs

@@ -34,9 +34,11 @@ class RuntimeEmitMixin:
             "#if defined(__HIP_DEVICE_COMPILE__)",
             "#define GRID_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)",
             "#define GRID_LAUNDER(x) asm volatile(\"\" : \"+v\"(x))   // same value, new identity: defeats CSE of deliberate recomputation",
+            "#define GRID_KEEP(x) asm volatile(\"\" :: \"v\"(x))       // the value must exist at this point of the instruction stream",
             "#else",
             "#define GRID_SCHED_FENCE()",
             "#define GRID_LAUNDER(x) ((void)0)",
+            "#define GRID_KEEP(x) ((void)(x))",
             "#endif",
             "// single kernel timing helper code",
             "#define time_delta_us_timespec(start,end) (1e6*static_cast<double>(end.tv_sec - start.tv_sec)+1e-3*static_cast<double>(end.tv_nsec - start.tv_nsec))",
@@ -102,6 +104,8 @@ class RuntimeEmitMixin:
         waves = self.max_threads // WAVE  # any legal block shape may be launched with the documented LDS size
         self.gen_add_code_lines([
             "const int NUM_JOINTS = %d;" % n,
+            "// arithmetic of the kernels for T = float: f32 | f32+f64(Minv,qdd) [mixed] | f64",
+            "#define GRID_DTYPE_%s \"%s\"" % (self.file_namespace, {"fp32": "f32", "mixed": "f32+f64(Minv,qdd)", "fp64": "f64"}[self.precision]),
             "// lane-per-configuration: one wavefront (64 lanes) stages 64 configurations through LDS;",
             "// <ALG>_DYNAMIC_SHARED_MEM_COUNT is what a block of up to GRID_MAX_THREADS threads needs (in T elements);",
             "// the host wrappers request only ceil(threads/64) wave regions (grid_lds_bytes)",
@@ -155,7 +159,7 @@ class RuntimeEmitMixin:
     # ------------------------------------------------------------------------------------------
     def gen_lane_helpers(self):
         """Lane math + accessors + wave-level LDS staging (new in the MI355X design)."""
-        compute_f = "double" if self.precision == "fp64" else "float"
+        compute_f = "double" if self.precision == "fp64" else "float"      # "mixed": C = float, selected regions in D = double
         self.gen_add_code_lines([
             "// ---- lane math: compute type C (generation-time default for T=float: %s) ----" % compute_f,
             "template <typename T> struct grid_compute {typedef T type;};",
@@ -163,6 +167,8 @@ class RuntimeEmitMixin:
             "__host__ __device__ __forceinline__ float grid_fma(float a, float b, float c){return __builtin_fmaf(a,b,c);}",
             "__host__ __device__ __forceinline__ double grid_fma(double a, double b, double c){return __builtin_fma(a,b,c);}",
             "template <typename V2> __host__ __device__ __forceinline__ V2 grid_pk_fma(V2 a, V2 b, V2 c){return __builtin_elementwise_fma(a, b, c);}",
+            "__host__ __device__ __forceinline__ float grid_rcp(float a){return 1.0f/a;}",
+            "__host__ __device__ __forceinline__ double grid_rcp(double a){return 1.0/a;}",
         ])
         if self.trig == "f64":
             self.gen_add_code_lines([
@@ -198,10 +204,20 @@ class RuntimeEmitMixin:
             "__host__ __device__ __forceinline__ double grid_sin(double x){return sin(x);}",
             "__host__ __device__ __forceinline__ double grid_cos(double x){return cos(x);}",
             "",
+            "/** Block barrier of the tile-cooperative kernels: this wave's LDS writes are complete (lgkmcnt(0)) before it arrives, other",
+            " *  waves' LDS reads are issued after they leave.  Like grid_wave_sync it deliberately does NOT wait for outstanding global",
+            " *  stores (a workgroup-scope release fence would drain them at every barrier). */",
+            "__device__ __forceinline__ void grid_block_sync(){",
+            "    __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\");",
+            "    asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");",
+            "    __builtin_amdgcn_s_barrier();",
+            "    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");",
+            "}",
             "// ---- accessors the traced cores are written against ----",
             "template <typename T>",
             "struct grid_in_ptrs {",
-            "    const T *q_; const T *qd_; const T *u_; const T *qdd_; const T *Minv_; T *tab_;",
+            "    const T *q_; const T *qd_; const T *u_; const T *qdd_; const T *Minv_; T *tab_; T dt_;",
+            "    __host__ __device__ __forceinline__ T dt() const {return dt_;}       // time step of the rollout step cores",
             "    __host__ __device__ __forceinline__ T q(int i) const {return q_[i];}",
             "    __host__ __device__ __forceinline__ T qd(int i) const {return qd_[i];}",
             "    __host__ __device__ __forceinline__ T u(int i) const {return u_[i];}",
@@ -226,6 +242,19 @@ class RuntimeEmitMixin:
             "    __device__ __forceinline__ T Minv(int i) const {return Minv_[i];}",
             "    __device__ __forceinline__ void tab_put(int i, T v) const {tab_wave_[i*GRID_WAVE_SIZE + lane_] = v;}",
             "    __device__ __forceinline__ T tab_get(int i) const {int l = lane_; asm volatile(\"\" : \"+v\"(l)); return tab_wave_[i*GRID_WAVE_SIZE + l];}",
+            "};",
+            "// accessor of the tile-cooperative kernels: the waves of a block work on the SAME 64 configurations and exchange",
+            "// per-configuration values through one LDS region (value `slot` of lane l at slot*64 + l; conflict-free).  Reads go through",
+            "// a laundered lane index so that every xch_get is its own short-lived load (see grid_in_lds::tab_get).",
+            "template <typename T>",
+            "struct grid_in_coop {",
+            "    const T *q_; const T *qd_; const T *u_; T *xch_; int lane_;",
+            "    __device__ __forceinline__ T q(int i) const {return q_[i];}",
+            "    __device__ __forceinline__ T qd(int i) const {return qd_[i];}",
+            "    __device__ __forceinline__ T u(int i) const {return u_[i];}",
+            "    __device__ __forceinline__ void xch_put(int i, T v) const {xch_[i*GRID_WAVE_SIZE + lane_] = v;}",
+            "    __device__ __forceinline__ T xch_get(int i) const {int l = lane_; asm volatile(\"\" : \"+v\"(l)); return xch_[i*GRID_WAVE_SIZE + l];}",
+            "    __device__ __forceinline__ void barrier() const {grid_block_sync();}",
             "};",
             "// accessors of the two-pass (pipeline) kernels: the per-tile workspace is SoA, value `slot` of lane l at slot*64 + l",
             "template <typename T>",
@@ -290,6 +319,30 @@ class RuntimeEmitMixin:
             " *  per-element (cfg, i) pairs of the unrolled staging loops out of the tile loop (that pinned ~N registers across",
             " *  the whole straight-line core: Atlas RNEA went from 244 registers to 512 + 222 spills). */",
             "__device__ __forceinline__ int grid_opaque(int x){asm volatile(\"\" : \"+v\"(x)); return x;}",
+            "/** The same for a wave-uniform pointer (stays in an SGPR pair): `p + constant` can then be neither hoisted out of the tile loop",
+            " *  nor turned into an induction variable -- it is two scalar adds where it is used.",
+            " *  The result is a GLOBAL (address space 1) pointer: the round trip through integers would otherwise leave a generic pointer",
+            " *  and every access through it would become a flat_ instruction (counted in lgkmcnt as well: the wave-local LDS syncs",
+            " *  would then wait for the kernel's global stores). */",
+            "#if defined(__HIP_DEVICE_COMPILE__)",
+            "#define GRID_GLOBAL __attribute__((address_space(1)))",
+            "#else",
+            "#define GRID_GLOBAL",
+            "#endif",
+            "template <typename P> __device__ __forceinline__ GRID_GLOBAL P *grid_opaque_uniform(P *p){",
+            "    const unsigned long long a = reinterpret_cast<unsigned long long>(p);",
+            "    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));   // (free when already uniform)",
+            "    asm volatile(\"\" : \"+s\"(lo), \"+s\"(hi));",
+            "    return (GRID_GLOBAL P *)(((unsigned long long)hi << 32) | lo);",
+            "}",
+            "/** Element at (wave-uniform global pointer) + (32-bit per-lane BYTE offset): the form that maps to `global_* v_off, v_data, s[base]`. */",
+            "template <typename P> __device__ __forceinline__ GRID_GLOBAL P &grid_at(GRID_GLOBAL P *base, const unsigned byte_offset){",
+            "    return *(GRID_GLOBAL P *)((GRID_GLOBAL char *)base + byte_offset);",
+            "}",
+            "template <typename P> __device__ __forceinline__ const GRID_GLOBAL P &grid_at(const GRID_GLOBAL P *base, const unsigned byte_offset){",
+            "    return *(const GRID_GLOBAL P *)((const GRID_GLOBAL char *)base + byte_offset);",
+            "}",
+            "__device__ __forceinline__ int grid_opaque_uniform(int x){x = __builtin_amdgcn_readfirstlane(x); asm volatile(\"\" : \"+s\"(x)); return x;}",
             "/**",
             " * Load N values for each of the wave's W configurations (k0 .. k0+W-1, row stride `stride`):",
             " * all N flat coalesced global reads are issued back to back (one memory round trip, not N/4), land in LDS at the",
@@ -300,31 +353,36 @@ class RuntimeEmitMixin:
             "__device__ __forceinline__ void grid_load_tile(T *dst, const T *d_src, const int stride, const int k0, const grid_tile_iter &it,",
             "                                               const int NUM_TIMESTEPS, T *s_wave){",
             "    const int nvalid = min(it.W, NUM_TIMESTEPS - k0);",
-            "    const T *src = d_src + (size_t)k0*stride;          // wave-uniform base; per-lane offsets stay 32-bit",
+            "    const GRID_GLOBAL T *src = grid_opaque_uniform(d_src + (size_t)k0*stride);     // wave-uniform base; per-lane offsets stay 32-bit",
             "    const int lane = grid_opaque(it.lane);",
             "    T tmp[N];",
-            "    if (nvalid == it.W){    // full tile (wave-uniform): no per-element predicates",
-            "        if (stride == N){   // dense rows: the wave's W*N values are one contiguous block",
-            "            #pragma unroll",
-            "            for (int t = 0; t < N; t++){tmp[t] = src[(unsigned)(t*it.W + lane)];}",
-            "        }",
-            "        else {",
+            "    if (it.W == GRID_WAVE_SIZE && nvalid == GRID_WAVE_SIZE && stride == N){",
+            "        // whole wave, full tile, dense rows (the common case): the wave's 64*N values are one contiguous block and every",
+            "        // index is lane + a compile-time constant (immediate offsets; nothing for the compiler to hoist into SGPRs)",
+            "        #pragma unroll",
+            "        for (int t = 0; t < N; t++){tmp[t] = grid_at(src + t*GRID_WAVE_SIZE, (unsigned)lane*(unsigned)sizeof(T));}",
+            "        #pragma unroll",
+            "        for (int t = 0; t < N; t++){s_wave[lane + t*GRID_WAVE_SIZE] = tmp[t];}",
+            "    }",
+            "    else {",
+            "        const int Wo = grid_opaque_uniform(it.W);       // (opaque: the N products t*W are not hoisted into N SGPRs)",
+            "        if (nvalid == it.W){    // full tile (wave-uniform): no per-element predicates",
             "            #pragma unroll",
             "            for (int t = 0; t < N; t++){",
-            "                const int f = t*it.W + lane; const int cfg = f / N; const int i = f - cfg*N;",
+            "                const int f = t*Wo + lane; const int cfg = f / N; const int i = f - cfg*N;",
             "                tmp[t] = src[(unsigned)(cfg*stride + i)];",
             "            }",
             "        }",
-            "    }",
-            "    else {                  // ragged last tile",
-            "        #pragma unroll",
-            "        for (int t = 0; t < N; t++){",
-            "            const int f = t*it.W + lane; const int cfg = f / N; const int i = f - cfg*N;",
-            "            tmp[t] = (cfg < nvalid) ? src[(unsigned)(cfg*stride + i)] : static_cast<T>(0);",
+            "        else {                  // ragged last tile",
+            "            #pragma unroll",
+            "            for (int t = 0; t < N; t++){",
+            "                const int f = t*Wo + lane; const int cfg = f / N; const int i = f - cfg*N;",
+            "                tmp[t] = (cfg < nvalid) ? src[(unsigned)(cfg*stride + i)] : static_cast<T>(0);",
+            "            }",
             "        }",
+            "        #pragma unroll",
+            "        for (int t = 0; t < N; t++){s_wave[t*Wo + lane] = tmp[t];}",
             "    }",
-            "    #pragma unroll",
-            "    for (int t = 0; t < N; t++){s_wave[t*it.W + lane] = tmp[t];}",
             "    grid_wave_sync();",
             "    #pragma unroll",
             "    for (int i = 0; i < N; i++){dst[i] = s_wave[lane*N + i];}",
@@ -351,42 +409,47 @@ class RuntimeEmitMixin:
             "        constexpr int P = (LEN <= 1) ? 1 : (LEN <= 2) ? 2 : (LEN <= 4) ? 4 : (LEN <= 8) ? 8 : (LEN <= 16) ? 16 : (LEN <= 32) ? 32 : 64;",
             "        constexpr int G = GRID_WAVE_SIZE / P;",
             "        const int nvalid = min(W, NUM_TIMESTEPS - k0);",
-            "        const int g = lane / P; const int ii = lane % P;",
+            "        // ADDRESSING.  Every address below is (wave-uniform 64-bit base in SGPRs) + (one 32-bit per-lane element offset),",
+            "        // and both are derived from OPAQUE copies of k0 and of the lane id taken right here.  Without that, loop strength",
+            "        // reduction turns every store address of every flush site (they differ by constants beyond the 4 KB immediate",
+            "        // range) into its own 64-bit pointer induction variable of the tile loop: the Atlas-30 gradient kernels carried",
+            "        // ~100 such pointer pairs across the whole straight-line core -- 200 registers, most of them living in scratch and",
+            "        // read-modify-written at the loop latch (1126 VGPR + 183 SGPR spills, 1.7 KB scratch per lane; DESIGN.md section 9).",
+            "        const int ol = grid_opaque(lane);",
+            "        GRID_GLOBAL T *urow = grid_opaque_uniform(d_dst + (size_t)k0*ROW);      // row of the tile's first configuration, wave-uniform",
+            "        const int g = ol / P; const int ii = ol % P;",
             "        grid_wave_sync();",
             "        if (W != GRID_WAVE_SIZE){           // partial wavefront (block size not a multiple of 64): generic path",
-            "            for (int f = lane; f < nvalid*LEN; f += W){",
+            "            for (int f = ol; f < nvalid*LEN; f += W){",
             "                const int cfg = f / LEN; const int i = f - cfg*LEN;",
-            "                d_dst[(size_t)(k0 + cfg)*ROW + base + i] = s_wave[f];",
+            "                urow[(size_t)cfg*ROW + base + i] = s_wave[f];",
             "            }",
             "        }",
             "        else if (ii < LEN){",
             "            const T *src = s_wave + (g*LEN + ii);",
-            "            T *dst = d_dst + (size_t)k0*ROW + base + (unsigned)(g*ROW + ii);",
-            "            // partially unrolled on purpose: 8 LDS reads in flight, small code (full unrolling made the Atlas kernels",
-            "            // take 7-25 minutes to compile)",
+            "            GRID_GLOBAL T *ubase = urow + base;                  // wave-uniform",
+            "            const unsigned vob = (unsigned)(g*ROW + ii)*(unsigned)sizeof(T);   // per lane, BYTES, 32 bit: SGPR base + VGPR offset addressing",
             "            if (nvalid == GRID_WAVE_SIZE){   // full tile: no per-iteration predicate",
             "                constexpr int NIT = GRID_WAVE_SIZE/G;",
             "                if constexpr (NIT % 8 == 0){",
             "                    // groups of 8 written out by hand (8 LDS reads in flight, then 8 stores) so that the shape does not",
-            "                    // depend on the optimisation level (-O1 keeps a `#pragma unroll` loop rolled: one LDS round trip per",
-            "                    // element).  Addresses stay per-lane 64-bit VGPR pointers + constants: a wave-uniform SGPR base inside",
-            "                    // this divergent region faulted on the register-capped Atlas kernels (190 SGPR spills).",
+            "                    // depend on the optimisation level (-O1 keeps a `#pragma unroll` loop rolled: one LDS round trip per element)",
             "                    for (int t = 0; t < NIT; t += 8){",
-            "                        const T *s = src + t*G*LEN; T *d = dst + (size_t)t*(G*ROW);",
+            "                        const T *s = src + t*G*LEN; GRID_GLOBAL T *d = ubase + (size_t)t*(G*ROW);     // uniform advance (scalar adds)",
             "                        const T a0 = s[0*G*LEN], a1 = s[1*G*LEN], a2 = s[2*G*LEN], a3 = s[3*G*LEN];",
             "                        const T a4 = s[4*G*LEN], a5 = s[5*G*LEN], a6 = s[6*G*LEN], a7 = s[7*G*LEN];",
-            "                        d[0*G*ROW] = a0; d[1*G*ROW] = a1; d[2*G*ROW] = a2; d[3*G*ROW] = a3;",
-            "                        d[4*G*ROW] = a4; d[5*G*ROW] = a5; d[6*G*ROW] = a6; d[7*G*ROW] = a7;",
+            "                        grid_at(d + 0*G*ROW, vob) = a0; grid_at(d + 1*G*ROW, vob) = a1; grid_at(d + 2*G*ROW, vob) = a2; grid_at(d + 3*G*ROW, vob) = a3;",
+            "                        grid_at(d + 4*G*ROW, vob) = a4; grid_at(d + 5*G*ROW, vob) = a5; grid_at(d + 6*G*ROW, vob) = a6; grid_at(d + 7*G*ROW, vob) = a7;",
             "                    }",
             "                }",
             "                else {",
             "                    #pragma unroll",
-            "                    for (int t = 0; t < NIT; t++){dst[(unsigned)(t*G*ROW)] = src[t*G*LEN];}",
+            "                    for (int t = 0; t < NIT; t++){grid_at(ubase + (size_t)t*(G*ROW), vob) = src[t*G*LEN];}",
             "                }",
             "            }",
             "            else {",
             "                #pragma unroll 2",
-            "                for (int t = 0; t < GRID_WAVE_SIZE/G; t++){if (t*G + g < nvalid){dst[(unsigned)(t*G*ROW)] = src[t*G*LEN];}}",
+            "                for (int t = 0; t < GRID_WAVE_SIZE/G; t++){if (t*G + g < nvalid){grid_at(ubase + (size_t)t*(G*ROW), vob) = src[t*G*LEN];}}",
             "            }",
             "        }",
             "        grid_wave_sync();",
@@ -419,6 +482,25 @@ class RuntimeEmitMixin:
             "            const int base = (chunk < NC) ? N*cols[chunk] : N*N + N*cols[chunk - NC];",
             "            grid_out_staged<T,ROW,N,N,0,N,0> run = {s_wave, d_dst, k0, lane, W, NUM_TIMESTEPS};",
             "            run.template flush_len<N>(base);",
+            "        }",
+            "    }",
+            "};",
+            "/**",
+            " * Staged sink whose output row is written in chunks of CH values that may arrive in ANY order: chunk k of the emission",
+            " * goes to row offset BASES[k] (rollout step cores: x+, then columns of A and B as the column-serial schedule produces",
+            " * them).  The values of chunk 0 are also kept in x_next (the integrator state the lane carries to the next step).",
+            " */",
+            "template <typename T, int ROW, int CH, int... BASES>",
+            "struct grid_out_chunks {",
+            "    T *s_wave; T *d_dst; int k0; int lane; int W; int NUM_TIMESTEPS; T *x_next;",
+            "    __device__ __forceinline__ void put(const int i, const T v){",
+            "        constexpr int NB = sizeof...(BASES);",
+            "        constexpr int bases[NB] = {BASES...};",
+            "        if (i < CH){x_next[i] = v;}",
+            "        s_wave[lane*CH + (i % CH)] = v;",
+            "        if (((i + 1) % CH) == 0){",
+            "            grid_out_staged<T,ROW,CH,CH,0,CH,0> run = {s_wave, d_dst, k0, lane, W, NUM_TIMESTEPS};",
+            "            run.template flush_len<CH>(bases[i / CH]);",
             "        }",
             "    }",
             "};",

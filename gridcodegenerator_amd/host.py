@@ -12,6 +12,7 @@ layouts (``q_qd_u[K][3n]`` in; ``c``, ``Minv``, ``qdd``, ``dc_du``, ``df_du`` ou
 import ctypes
 import hashlib
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -28,6 +29,9 @@ CSRC = os.path.join(PKG_DIR, "csrc", "grid_capi.hip")
 KERNEL_INST_SRC = os.path.join(PKG_DIR, "csrc", "grid_kernel_inst.hip")
 INCLUDE_DIR = os.path.join(REPO_DIR, "include")
 ARCH = "gfx950"
+# arithmetic variants whose kernels pass the GPU parity tests (precision="fp64" is refused by the generator)
+VERIFIED_PRECISIONS = ("fp32", "mixed")
+DEFAULT_PRECISION = "fp32"
 
 ALG_ID, ALG_MINV, ALG_FD, ALG_ID_DU, ALG_FD_DU = range(5)
 ALG_NAMES = {ALG_ID: "inverse_dynamics", ALG_MINV: "direct_minv", ALG_FD: "forward_dynamics",
@@ -67,6 +71,123 @@ def library_paths(robot_name, precision="fp32"):
                 log=os.path.join(BUILD_DIR, "grid_%s.build.log" % tag))
 
 
+_QUALIFIER_LINE = re.compile(r"^\s*(template\s*<.*>|__host__|__device__|__global__|inline|__forceinline__|__launch_bounds__\(.*\)|\s)+$")
+
+
+def _header_blocks(text):
+    """Cut a generated header into (name, text) blocks at the function doc comments (`/**` at namespace indentation).
+    name = the function the block defines (None for anything else: constants, structs, helper templates)."""
+    lines = text.splitlines(keepends=True)
+    starts = [i for i, l in enumerate(lines) if l.startswith("    /**")]
+    bounds = [0] + starts + [len(lines)]
+    blocks = []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        if a == b:
+            continue
+        chunk = lines[a:b]
+        name = None
+        i = 0
+        if chunk[0].startswith("    /**"):
+            while i < len(chunk) and "*/" not in chunk[i]:
+                i += 1
+            i += 1
+            while i < len(chunk) and _QUALIFIER_LINE.match(chunk[i]):
+                i += 1
+            if i < len(chunk):
+                m = re.match(r"\s*struct\s+(\w+)", chunk[i]) or re.search(r"(\w+)\s*\(", chunk[i])
+                name = m.group(1) if m else None
+        blocks.append((name, "".join(chunk)))
+    return blocks
+
+
+def kernel_dependency_hashes(header_text, kernel_names):
+    """For each kernel name: a hash of the part of the generated header its translation unit depends on -- everything
+    outside the algorithm section (constants, structs, lane/staging helpers, init/close) plus the transitive closure of the
+    algorithm functions (cores, _device, launchers ...) the kernel's text mentions.  Adding or changing ANOTHER kernel
+    family then leaves this kernel's object cache entry valid (an Atlas-30 gradient kernel takes minutes to compile)."""
+    blocks = _header_blocks(header_text)
+    names = [b[0] for b in blocks]
+    try:
+        first = names.index("load_update_XImats_helpers")
+        last = names.index("init_grid")
+    except ValueError:
+        whole = hashlib.sha256(header_text.encode()).hexdigest()
+        return {k: whole for k in kernel_names}
+    outside = "".join(t for (nm, t) in blocks[:first] + blocks[last:])
+    # the explicit-instantiation macros at the end name every kernel: keep only the lines that are not per-kernel macros
+    outside = "\n".join(l for l in outside.splitlines() if not l.startswith("#define GRID_KERNEL_INST_")
+                        and not l.startswith("#define GRID_FOR_EACH_KERNEL_INST") and not l.startswith("#define GRID_NUM_KERNEL_INSTANCES"))
+    region = blocks[first:last]
+    by_name = {}
+    for idx, (nm, t) in enumerate(region):
+        if nm is not None:
+            by_name.setdefault(nm, []).append(idx)
+    ident = re.compile(r"\b[A-Za-z_]\w*\b")
+    refs = []
+    for (nm, t) in region:
+        found = set(w for w in ident.findall(t) if w in by_name and w != nm)
+        refs.append(found)
+    out = {}
+    for k in kernel_names:
+        seen = set()
+        stack = [k]
+        while stack:
+            nm = stack.pop()
+            if nm in seen or nm not in by_name:
+                continue
+            seen.add(nm)
+            for idx in by_name[nm]:
+                stack.extend(refs[idx])
+        h = hashlib.sha256(outside.encode())
+        for idx, (nm, t) in enumerate(region):
+            if nm in seen or nm is None:
+                h.update(t.encode())
+        out[k] = h.hexdigest()
+    return out
+
+
+# Build-time resource guard.  The round-1 GPU failures (a memory fault, silently wrong numbers, hangs: DESIGN.md section 9) all came
+# from kernels that hipcc could only build with kilobytes of scratch per lane and hundreds of SGPR spills; nothing that heavy is
+# allowed into a library any more unless the caller explicitly builds an unverified variant.
+MAX_SCRATCH_BYTES_PER_LANE = 1024
+MAX_SGPR_SPILLS = 128
+
+
+def parse_kernel_resources(log_text):
+    """-Rpass-analysis=kernel-resource-usage remarks of a build log -> [{name, sgprs, vgprs, agprs, scratch, occupancy,
+    sgpr_spills, vgpr_spills}] (one entry per compiled kernel, overloads included)."""
+    out = []
+    cur = None
+    keys = {"TotalSGPRs": "sgprs", "VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSize [bytes/lane]": "scratch",
+            "Occupancy [waves/SIMD]": "occupancy", "SGPRs Spill": "sgpr_spills", "VGPRs Spill": "vgpr_spills"}
+    for line in log_text.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            mangled = m.group(1)
+            nm = re.match(r"_ZN\d+\w+?(\d+)(\w+)", mangled)
+            name = mangled
+            mm = re.match(r"_ZN(\d+)", mangled)
+            if mm:      # _ZN<len><namespace><len><function>...
+                i = 3 + len(mm.group(1)) + int(mm.group(1))
+                m2 = re.match(r"(\d+)", mangled[i:])
+                if m2:
+                    j = i + len(m2.group(1))
+                    name = mangled[j:j + int(m2.group(1))]
+            cur = {"name": name, "mangled": mangled}
+            out.append(cur)
+            continue
+        m = re.search(r"remark:\s+([A-Za-z \[\]/]+): (\d+)", line)
+        if m and cur is not None and m.group(1).strip() in keys:
+            cur[keys[m.group(1).strip()]] = int(m.group(2))
+    return out
+
+
+def kernel_resources(robot_name, precision="fp32"):
+    """Compiler-reported resources of every kernel of a built library (from its build log)."""
+    with open(library_paths(robot_name, precision)["log"]) as fh:
+        return parse_kernel_resources(fh.read())
+
+
 def generate_header(robot, path, namespace, **gen_kwargs):
     """Run the generator for ``robot`` and move ``<namespace>.hip.h`` (written to the CWD, as the
     reference writes grid.cuh to the CWD, GRiDCodeGenerator.py:308) to ``path``."""
@@ -97,7 +218,7 @@ def build_library(robot_name, precision="fp32", force=False, verbose=False, extr
 
 
 # generator options used when a built-in robot is built without explicit options (tests rely on these)
-DEFAULT_GEN_KWARGS = {"mixed5": {"pipeline": True, "grad_schedule": "recompute", "grad_table": True, "split_sets": True}}   # the small test robot exercises the two-pass kernels and the recomputing (LDS table) schedule, prismatic joints included
+DEFAULT_GEN_KWARGS = {"mixed5": {"pipeline": True, "grad_schedule": "recompute", "experimental": {"grad_table": True, "split_sets": True}}}   # the small test robot exercises the two-pass kernels and the recomputing (LDS table) schedule, prismatic joints included
 
 
 def _build_library_locked(robot_name, precision, force, verbose, extra_flags, gen_kwargs):
@@ -121,14 +242,17 @@ def _build_library_locked(robot_name, precision, force, verbose, extra_flags, ge
 
     flags = ["--offload-arch=" + ARCH, opt, "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-I" + INCLUDE_DIR] + list(extra_flags)
     # (no absolute paths in the fingerprint: the same tree is mounted at different locations on different boxes)
-    fp = _source_fingerprint(repr(sorted(gen_kwargs.items())) + precision + " ".join(f for f in flags if not f.startswith("-I")))
+    robot_obj = get_robot(robot_name)
+    model_hash = hashlib.sha256(repr([(robot_obj.get_parent_id(j), robot_obj.get_damping_by_id(j), np.asarray(robot_obj.get_Imat_by_id(j)).tolist(),
+                                       np.asarray(robot_obj.get_Xmat_Func_by_id(j)(0.3)).tolist()) for j in range(robot_obj.get_num_pos())]).encode()).hexdigest()
+    fp = _source_fingerprint(repr(sorted(gen_kwargs.items())) + precision + model_hash + " ".join(f for f in flags if not f.startswith("-I")))
     if not force and os.path.exists(p["lib"]) and os.path.exists(p["stamp"]):
         with open(p["stamp"]) as fh:
             if fh.read().strip() == fp:
                 return p["lib"]
     os.makedirs(BUILD_DIR, exist_ok=True)
     ns = "grid_" + robot_name
-    gen = generate_header(get_robot(robot_name), p["header"], ns, precision=precision, **gen_kwargs)
+    gen = generate_header(robot_obj, p["header"], ns, precision=precision, **gen_kwargs)
     # one translation unit per kernel + the C-ABI unit, compiled in parallel, then linked
     common = [_hipcc()] + [f for f in flags if f != "-shared"] + [
         "-c", "-DGRID_HEADER=\"%s\"" % p["header"], "-DGRID_NS=" + ns, "-DGRID_ROBOT_NAME=\"%s\"" % robot_name,
@@ -143,15 +267,24 @@ def _build_library_locked(robot_name, precision, force, verbose, extra_flags, ge
     # per-object cache: an object is reused when the generated header, its own source and the flags are unchanged (a C-ABI
     # edit then recompiles capi.o only -- the largest Atlas-30 kernel alone takes ~20 minutes)
     with open(p["header"], "rb") as fh:
-        header_hash = hashlib.sha256(fh.read()).hexdigest()
+        header_bytes = fh.read()
+    header_hash = hashlib.sha256(header_bytes).hexdigest()
+    inst_names = [decl.split("::")[1].split("<")[0] for decl in gen.kernel_instances]
+    dep_hash = kernel_dependency_hashes(header_bytes.decode(), set(inst_names))
 
     def object_key(cmd):
-        h = hashlib.sha256(header_hash.encode())
+        inst = next((a for a in cmd if a.startswith("-DGRID_INST=")), None)
+        # a kernel object depends on its own slice of the header (and its instantiation line); the C-ABI unit on all of it
+        if inst is not None:
+            k = int(inst.split("=")[1])
+            h = hashlib.sha256((dep_hash[inst_names[k]] + gen.kernel_instances[k]).encode())
+        else:
+            h = hashlib.sha256(header_hash.encode())
         with open(cmd[-3], "rb") as fh:
             h.update(fh.read())
         with open(os.path.join(INCLUDE_DIR, "grid_capi.h"), "rb") as fh:
             h.update(fh.read())
-        h.update(" ".join(a for a in cmd[1:-3] if not a.startswith("-I") and not a.startswith("-DGRID_HEADER=")).encode())
+        h.update(" ".join(a for a in cmd[1:-3] if not a.startswith("-I") and not a.startswith("-DGRID_HEADER=") and not a.startswith("-DGRID_INST=")).encode())
         return h.hexdigest()
 
     def run(job):
@@ -182,6 +315,14 @@ def _build_library_locked(robot_name, precision, force, verbose, extra_flags, ge
     for (name, cmd, rc, out) in results:
         if rc != 0:
             raise GridLibraryError("hipcc failed for %s/%s (see %s):\n%s" % (p["tag"], name, p["log"], out[-4000:]))
+    if not gen_kwargs.get("allow_unverified"):
+        for (name, cmd, rc, out) in results:
+            for k in parse_kernel_resources(out):
+                if k.get("scratch", 0) > MAX_SCRATCH_BYTES_PER_LANE or k.get("sgpr_spills", 0) > MAX_SGPR_SPILLS:
+                    raise GridLibraryError(
+                        "%s: kernel %s needs %d B of scratch per lane and %d SGPR spills (limits %d / %d): builds this heavy faulted or "
+                        "miscomputed on the GPU (DESIGN.md section 9); pass allow_unverified=True to build it anyway"
+                        % (p["tag"], k["name"], k.get("scratch", 0), k.get("sgpr_spills", 0), MAX_SCRATCH_BYTES_PER_LANE, MAX_SGPR_SPILLS))
     link = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC"] + [j[1][-1] for j in jobs] + ["-o", p["lib"] + ".tmp"]
     proc = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     with open(p["log"], "a") as fh:
@@ -192,6 +333,41 @@ def _build_library_locked(robot_name, precision, force, verbose, extra_flags, ge
     with open(p["stamp"], "w") as fh:
         fh.write(fp)
     return p["lib"]
+
+
+API_HARNESS_SRC = os.path.join(REPO_DIR, "tests", "api_surface_harness.hip")
+
+
+def api_harness_path(robot_name, precision="fp32"):
+    return os.path.join(BUILD_DIR, "libapi_harness_%s_%s.so" % (robot_name, precision))
+
+
+def build_api_harness(robot_name, precision="fp32", force=False):
+    """TEST INFRASTRUCTURE: compile tests/api_surface_harness.hip (user-style code over the generated header: _compute_only /
+    _launch / USE_COMPRESSED_MEM wrappers, _device and _inner tiers inside user kernels) against the robot's header, linked
+    with its kernel library.  Built here so that the GPU box only has to load it.  Returns the .so path."""
+    lib = build_library(robot_name, precision)
+    p = library_paths(robot_name, precision)
+    out = api_harness_path(robot_name, precision)
+    h = hashlib.sha256()
+    for fn in (p["header"], API_HARNESS_SRC):
+        with open(fn, "rb") as fh:
+            h.update(fh.read())
+    key = h.hexdigest()
+    if not force and os.path.exists(out) and os.path.exists(out + ".key"):
+        with open(out + ".key") as fh:
+            if fh.read().strip() == key:
+                return out
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O1", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+           "-DGRID_HEADER=\"%s\"" % p["header"], "-DGRID_NS=grid_" + robot_name, "-DGRID_EXTERN_KERNELS", API_HARNESS_SRC,
+           "-L" + BUILD_DIR, "-l" + os.path.basename(lib)[3:-3], "-Wl,-rpath,$ORIGIN", "-o", out + ".tmp"]
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if proc.returncode != 0:
+        raise GridLibraryError("hipcc failed for the API-surface harness of %s:\n%s" % (robot_name, proc.stdout[-4000:]))
+    os.replace(out + ".tmp", out)
+    with open(out + ".key", "w") as fh:
+        fh.write(key)
+    return out
 
 
 _c_float_p = ctypes.POINTER(ctypes.c_float)
@@ -221,14 +397,22 @@ CAPI_SIGNATURES = [
     ("grid_inverse_dynamics_gradient_device", ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, _vp]),
     ("grid_forward_dynamics_gradient_device", ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, _vp]),
     ("grid_synchronize", ctypes.c_int, [_vp, _vp]),
+    ("grid_rollout_row_count", ctypes.c_int, []),
+    ("grid_forward_dynamics_gradient_rollout_device", ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,
+                                                                     ctypes.c_int, ctypes.c_int, _vp]),
     ("grid_splits", ctypes.c_int, [ctypes.c_int, _c_int_p, ctypes.c_int]),
     ("grid_set_split", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     ("grid_get_split", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
+    ("grid_coop_available", ctypes.c_int, [ctypes.c_int]),
+    ("grid_set_coop", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
+    ("grid_get_coop", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
+    ("grid_kernel_attributes_coop", ctypes.c_int, [ctypes.c_int, _c_int_p]),
     ("grid_workspace_count", ctypes.c_int, [ctypes.c_int]),
     ("grid_set_pipeline", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     ("grid_time_device", ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_float,
                                         ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _c_float_p]),
     ("grid_kernel_attributes", ctypes.c_int, [ctypes.c_int, ctypes.c_int, _c_int_p]),
+    ("grid_kernel_attributes_split", ctypes.c_int, [ctypes.c_int, ctypes.c_int, _c_int_p]),
 ]
 
 
@@ -268,9 +452,16 @@ class GridLibrary:
         k = self.lib.grid_splits(alg, out, 16)
         return [int(out[i]) for i in range(k)]
 
-    def kernel_attributes(self, alg, variant=0):
+    def kernel_attributes(self, alg, variant=0, split=0, coop=False):
+        """Resources of the kernel for `alg`: variant 1 = the qdd / qdd+Minv input variant; split = S > 1: the S-way
+        column-split kernel (what grid_get_split says a call dispatches); coop: the tile-cooperative kernel."""
         out = (ctypes.c_int * 4)()
-        self.check(self.lib.grid_kernel_attributes(alg, variant, out), "grid_kernel_attributes")
+        if coop:
+            self.check(self.lib.grid_kernel_attributes_coop(alg, out), "grid_kernel_attributes_coop")
+        elif split > 1:
+            self.check(self.lib.grid_kernel_attributes_split(alg, split, out), "grid_kernel_attributes_split")
+        else:
+            self.check(self.lib.grid_kernel_attributes(alg, variant, out), "grid_kernel_attributes")
         return dict(numRegs=out[0], static_lds_bytes=out[1], scratch_bytes_per_lane=out[2], maxThreadsPerBlock=out[3])
 
 
@@ -394,9 +585,28 @@ class GridHandle:
         self.L.check(self.L.lib.grid_forward_dynamics_gradient_device(self._h, d_df_du, d_q_qd_u, stride, d_qdd, d_Minv, K, gravity,
                                                                       blocks, threads, stream), "grid_forward_dynamics_gradient_device")
 
+    def forward_dynamics_gradient_rollout_device(self, d_traj, d_x0, d_u_traj, K, num_steps, dt, gravity=9.81, blocks=0, threads=0, stream=None):
+        """Semi-implicit Euler rollout with linearisation (include/grid_capi.h): d_traj is time-major
+        [num_steps][K][rollout_row_count] = [x+ | A | B] per step."""
+        self.L.check(self.L.lib.grid_forward_dynamics_gradient_rollout_device(self._h, d_traj, d_x0, d_u_traj, K, num_steps, dt, gravity,
+                                                                               blocks, threads, stream), "grid_forward_dynamics_gradient_rollout_device")
+
+    def rollout_row_count(self):
+        return int(self.L.lib.grid_rollout_row_count())
+
     def set_split(self, alg, split):
         """0 = automatic (default), 1 = never split, S = force the S-way column-split kernel."""
         self.L.check(self.L.lib.grid_set_split(self._h, alg, int(split)), "grid_set_split")
+
+    def set_coop(self, alg, mode):
+        """Tile-cooperative kernel: 0 = automatic (default), 1 = never, 2 = always."""
+        self.L.check(self.L.lib.grid_set_coop(self._h, alg, int(mode)), "grid_set_coop")
+
+    def get_coop(self, alg, K):
+        return int(self.L.lib.grid_get_coop(self._h, alg, int(K))) == 1
+
+    def coop_available(self, alg):
+        return int(self.L.lib.grid_coop_available(alg)) == 1
 
     def set_pipeline(self, alg, mode):
         """0 = automatic (single kernel), 1 = single kernel, 2 = two-pass (workspace) variant."""

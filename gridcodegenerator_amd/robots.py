@@ -108,8 +108,27 @@ def chain_prismatic_test_robot():
 BUILTIN_ROBOTS = {"iiwa7": iiwa7, "atlas30": atlas30, "mixed5": chain_prismatic_test_robot}
 
 
+REGISTERED_ROBOTS = {}
+
+
+def register_robot(name, factory):
+    """Make a robot object (e.g. one loaded from a URDF file with gridcodegenerator_amd.urdf.load_urdf) available to
+    host.build_library / GridHandle under `name`: factory() -> robot object."""
+    if name in BUILTIN_ROBOTS:
+        raise ValueError("%r is a built-in robot" % name)
+    if not name.replace("_", "").isalnum():
+        raise ValueError("robot names become C++ namespaces and file names: letters, digits and underscores only")
+    REGISTERED_ROBOTS[name] = factory
+
+
+def register_urdf(name, path):
+    from .urdf import load_urdf
+    register_robot(name, lambda: load_urdf(path))
+
+
 def get_robot(name):
-    try:
+    if name in BUILTIN_ROBOTS:
         return BUILTIN_ROBOTS[name]()
-    except KeyError:
-        raise KeyError("unknown built-in robot %r (have %s)" % (name, sorted(BUILTIN_ROBOTS)))
+    if name in REGISTERED_ROBOTS:
+        return REGISTERED_ROBOTS[name]()
+    raise KeyError("unknown robot %r (built in: %s; registered: %s)" % (name, sorted(BUILTIN_ROBOTS), sorted(REGISTERED_ROBOTS)))

@@ -76,6 +76,17 @@ int grid_forward_dynamics_gradient_device(grid_handle *h, float *d_df_du, const 
                                           int num_timesteps, float gravity, int blocks, int threads, void *stream);
 int grid_synchronize(grid_handle *h, void *stream);
 
+/* ---- rollout consumer of the forward-dynamics gradient (no reference kernel; the reference ships the `_device` tier for
+ * exactly this use, README.md:26-29, algorithms/_forward_dynamics_gradient.py:59-99) ----
+ * One lane integrates one trajectory for num_steps semi-implicit Euler steps (qdd = FD(q, qd, u_t); qd += dt qdd; q += dt qd)
+ * with q, qd kept in registers, and writes per step the next state and the discrete linearisation:
+ *   d_traj[(t*num_timesteps + k)*grid_rollout_row_count() + ...] = [x_{t+1} (2n) | A_t (2n x 2n col-major) | B_t (2n x n col-major)]
+ *   d_x0[k][2n] = [q | qd];  d_u_traj[(t*num_timesteps + k)*n + j]   (both time-major, dense).  Asynchronous on `stream`. */
+int grid_rollout_row_count(void);
+int grid_forward_dynamics_gradient_rollout_device(grid_handle *h, float *d_traj, const float *d_x0, const float *d_u_traj,
+                                                  int num_timesteps, int num_steps, float dt, float gravity,
+                                                  int blocks, int threads, void *stream);
+
 /* ---- column-split variants of the two gradient kernels (no reference counterpart) ----
  * For small batches the chip is under-filled with one lane per configuration; the generator therefore also emits
  * kernels in which S blocks share a tile and each computes a group of gradient columns (repeating the common prefix).
@@ -85,13 +96,28 @@ int grid_splits(int alg, int *out, int count);
 int grid_set_split(grid_handle *h, int alg, int split);
 int grid_get_split(grid_handle *h, int alg, int num_timesteps);
 
+/* ---- tile-cooperative forward-dynamics-gradient kernel (no reference counterpart; the regime it serves is the reference's own:
+ * one thread block per configuration, GRiDCodeGenerator.py:72-83, algorithms/_forward_dynamics_gradient.py:7-57) ----
+ * One block of 4 wavefronts per tile of 64 configurations: one wave runs the Minv recursion while the others run RNEA, the
+ * results cross through LDS, then every wave differentiates its own group of columns.  Unlike the column-split kernels the
+ * shared prefix is computed ONCE per tile.  grid_coop_available: 1 if the generator emitted it for `alg` (GRID_ALG_FD_DU).
+ * grid_set_coop: 0 = automatic (default: chosen per batch size from measurements), 1 = never, 2 = always.
+ * grid_get_coop: 1 if a call with `num_timesteps` would dispatch it (it takes precedence over the column split). */
+int grid_coop_available(int alg);
+int grid_set_coop(grid_handle *h, int alg, int mode);
+int grid_get_coop(grid_handle *h, int alg, int num_timesteps);
+int grid_kernel_attributes_coop(int alg, int *out);
+
 /* ---- two-pass (workspace) variants of the gradient kernels (no reference counterpart) ----
  * For robots whose gradient working set exceeds the register file (Atlas-30) the generator also emits a two-kernel
  * variant: pass 1 (RNEA [+ Minv, qdd]) writes per-joint quantities to a tile-major SoA workspace in HBM, pass 2 runs the
  * gradient column by column re-reading them.  grid_workspace_count: elements per configuration (0 = not generated).
  * grid_set_pipeline: 0 = automatic (single kernel: measured faster since the recomputing column schedule), 1 = single kernel,
  * 2 = two-pass (error when the generator emitted none for this robot).
- * The workspace lives in the handle and grows on demand (first call at a new batch size allocates). */
+ * The workspace lives in the handle and grows on demand (first call at a new batch size allocates).  ONE workspace serves
+ * both gradient algorithms: a two-pass launch on a stream other than the one that used it last first waits for that
+ * stream (hipStreamSynchronize), and growth waits for the whole device -- neither is graph-capturable; the single-kernel
+ * default has no such state. */
 int grid_workspace_count(int alg);
 int grid_set_pipeline(grid_handle *h, int alg, int mode);
 
@@ -104,6 +130,9 @@ int grid_time_device(grid_handle *h, int alg, float *d_out, const float *d_in, i
 /* hipFuncGetAttributes of the kernel for `alg` (variant: 0 default inputs, 1 with qdd / qdd+Minv):
  * out[0]=numRegs out[1]=static LDS bytes out[2]=scratch (local) bytes per lane out[3]=maxThreadsPerBlock */
 int grid_kernel_attributes(int alg, int variant, int *out);
+/* the same for the S-way column-split kernel of a gradient algorithm (the kernel grid_get_split() says a call dispatches);
+ * split <= 1 is the unsplit kernel; an S that was not generated is an error */
+int grid_kernel_attributes_split(int alg, int split, int *out);
 
 #ifdef __cplusplus
 }

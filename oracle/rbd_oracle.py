@@ -12,6 +12,8 @@ What it restates: the numpy reference algorithms the generator authors mixed int
     minv_bpass / minv_fpass / minv      <- _test.py:117-184, 186-202, 204-226
     rnea_grad_inner / rnea_grad         <- _test.py:229-488, 490-494
     fd_grad                             <- _test.py:496-520
+    rollout_step / rollout              <- no reference counterpart (consumer of forward_dynamics_gradient_device,
+                                           README.md:26-29); defined here from fd_grad and minv
     mxS / fxv / fx                      <- _test.py:522-664
 
 Differences from the reference text (behaviour identical unless stated):
@@ -403,6 +405,41 @@ def fd_grad(T, q, qd, u, gravity=9.81, prismatic_fix=True, return_parts=False):
 # ----------------------------------------------------------------------------------------------
 # boundary layouts (SURVEY.md section 8(b)): what the kernels read / write, flattened
 # ----------------------------------------------------------------------------------------------
+def rollout_step(T, q, qd, u, dt, gravity=9.81):
+    """One semi-implicit Euler step of the forward dynamics and its linearisation (the consumer the reference's _device tier
+    exists for, README.md:26-29; there is no reference implementation of it -- this is the definition the HIP rollout
+    kernel is tested against):
+
+        qdd = FD(q, qd, u);   qd+ = qd + dt qdd;   q+ = q + dt qd+        x = [q; qd]
+        A = dx+/dx = [[I + dt^2 dqdd/dq,  dt I + dt^2 dqdd/dqd], [dt dqdd/dq,  I + dt dqdd/dqd]]      (2n x 2n)
+        B = dx+/du = [[dt^2 Minv], [dt Minv]]                                                         (2n x n)
+
+    Returns (q+, qd+, A, B), batched."""
+    q, qd, u = _as_batch(q, qd, u)
+    n = q.shape[1]
+    df, parts = fd_grad(T, q, qd, u, gravity, return_parts=True)
+    qdd, Minv = parts["qdd"], parts["Minv"]
+    qd_next = qd + dt * qdd
+    q_next = q + dt * qd_next
+    I = np.eye(n)[None]
+    dq, dqd = df[:, :, :n], df[:, :, n:]
+    A = np.concatenate([np.concatenate([I + dt * dt * dq, dt * I + dt * dt * dqd], axis=2),
+                        np.concatenate([dt * dq, I + dt * dqd], axis=2)], axis=1)
+    B = np.concatenate([dt * dt * Minv, dt * Minv], axis=1)
+    return q_next, qd_next, A, B
+
+
+def rollout(T, q0, qd0, u_traj, dt, gravity=9.81):
+    """T-step rollout from (q0, qd0) under u_traj[t] (shape (steps, K, n)).  Returns x (steps, K, 2n) = the states AFTER each
+    step, A (steps, K, 2n, 2n), B (steps, K, 2n, n)."""
+    q, qd = _as_batch(q0, qd0)
+    xs, As, Bs = [], [], []
+    for t in range(u_traj.shape[0]):
+        q, qd, A, B = rollout_step(T, q, qd, u_traj[t], dt, gravity)
+        xs.append(np.concatenate([q, qd], axis=1)); As.append(A); Bs.append(B)
+    return np.stack(xs), np.stack(As), np.stack(Bs)
+
+
 def pack_q_qd_u(q, qd, u):
     """[K][3n] = [q | qd | u]."""
     return np.concatenate([q, qd, u], axis=1)

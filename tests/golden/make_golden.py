@@ -115,5 +115,52 @@ def main():
         print("wrote", path, {k: np.asarray(v).shape for k, v in out.items() if k in ("df_du", "h_XImats", "h_topology_helpers")})
 
 
+def reference_signatures():
+    """The argument lists of every kernel / _device / host function the REFERENCE emits for each robot, recorded as data
+    (tests/golden/reference_signatures.json): the drop-in boundary the generated HIP header must reproduce (names, argument
+    order and types; cudaStream_t becomes hipStream_t).  Only declaration lines are kept -- no function bodies."""
+    import json
+    import tempfile
+    out = {}
+    for name in SEEDS:
+        g = RefGen(get_robot(name))
+        cwd = os.getcwd()
+        with tempfile.TemporaryDirectory() as d:
+            os.chdir(d)
+            try:
+                with contextlib.redirect_stdout(io.StringIO()):
+                    g.gen_all_code()
+                code = g.code_str
+            finally:
+                os.chdir(cwd)
+        lines = code.splitlines()
+        sigs = {"kernel": [], "device": [], "host": []}
+        for i, line in enumerate(lines):
+            q = line.strip()
+            if q in ("__global__", "__device__", "__host__"):
+                j = i + 1
+                decl = lines[j].strip()
+                while not decl.endswith("{") and j + 1 < len(lines):      # host wrappers span two lines
+                    j += 1
+                    decl += " " + lines[j].strip()
+                decl = re.sub(r"\s+", " ", decl.rstrip("{").strip())
+                if not decl.startswith("void "):
+                    continue
+                fname = decl.split("(")[0].split()[-1]
+                if q == "__global__":
+                    sigs["kernel"].append(decl)
+                elif q == "__device__" and fname.endswith("_device"):
+                    sigs["device"].append(decl)
+                elif q == "__host__" and not fname.startswith(("init_", "close_", "gpuAssert")):
+                    sigs["host"].append(decl)
+        out[name] = {k: sorted(set(v)) for k, v in sigs.items()}
+    path = os.path.join(HERE, "reference_signatures.json")
+    with open(path, "w") as fh:
+        json.dump(out, fh, indent=1, sort_keys=True)
+    print("wrote", path, {k: {kk: len(vv) for kk, vv in v.items()} for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    main()
+    if "--signatures-only" not in sys.argv:
+        main()
+    reference_signatures()

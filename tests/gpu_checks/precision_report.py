@@ -1,0 +1,40 @@
+"""Measured error of every kernel output against the float64 oracle, per robot: norm-wise (max|err| / max|ref| over the
+batch) and worst element-wise.  usage: python tests/gpu_checks/precision_report.py [precision] [robots...]"""
+import json
+import sys
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import numpy as np
+from conftest import make_inputs, relerr
+from gridcodegenerator_amd import host
+from gridcodegenerator_amd.robots import get_robot
+from oracle import rbd_oracle as O
+
+precision = sys.argv[1] if len(sys.argv) > 1 else "fp32"
+robots = sys.argv[2:] or ["iiwa7", "atlas30", "mixed5"]
+report = {}
+for robot in robots:
+    host.build_library(robot, precision)
+    h = host.GridHandle(robot, precision=precision)
+    n = h.n
+    T = O.RobotTables(get_robot(robot))
+    for (K, seed) in ((201, 31), (2048, 77)):
+        q, qd, u = make_inputs(n, K, seed)
+        q64, qd64, u64 = (a.astype(np.float64) for a in (q, qd, u))
+        x = np.ascontiguousarray(np.concatenate([q, qd, u], axis=1))
+        df, parts = O.fd_grad(T, q64, qd64, u64, return_parts=True)
+        gflat = lambda M: np.concatenate([O.flat_colmajor(M[:, :, :n]), O.flat_colmajor(M[:, :, n:])], axis=1)
+        qdd32 = parts["qdd"].astype(np.float32)
+        Minv32 = O.flat_colmajor(np.triu(parts["Minv"])).astype(np.float32)
+        res = {
+            "c": relerr(h.inverse_dynamics(x), parts["c"]),
+            "Minv": relerr(h.direct_minv(x), O.flat_colmajor(np.triu(parts["Minv"]))),
+            "qdd": relerr(h.forward_dynamics(x), parts["qdd"]),
+            "dc_du": relerr(h.inverse_dynamics_gradient(x), gflat(O.rnea_grad(T, q64, qd64, None))),
+            "dc_du_qdd": relerr(h.inverse_dynamics_gradient(x, qdd=qdd32), gflat(O.rnea_grad(T, q64, qd64, qdd32.astype(np.float64)))),
+            "df_du": relerr(h.forward_dynamics_gradient(x), gflat(df)),
+            "df_du_qdd_minv": relerr(h.forward_dynamics_gradient(x, qdd=qdd32, Minv=Minv32), gflat(df)),
+        }
+        report["%s:%d" % (robot, K)] = {k: [float(v[0]), float(v[1])] for k, v in res.items()}
+        print("%-8s K=%-5d %s" % (robot, K, "  ".join("%s %.2e/%.1e" % (k, v[0], v[1]) for k, v in res.items())), flush=True)
+    h.close()
+print(json.dumps({"precision": precision, "errors_normwise_elementwise": report}))

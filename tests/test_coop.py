@@ -1,0 +1,154 @@
+"""Tile-cooperative forward-dynamics-gradient kernel: one block of 4 wavefronts per tile of 64 configurations; one wave runs the
+Minv recursion while the others run RNEA, results cross through LDS (Minv, c, qdd), every wave then differentiates its own
+group of columns (gridcodegenerator_amd/emit/cores.py: core_forward_dynamics_gradient_coop / core_gradient_recompute(coop=...)).
+The regime it replaces is the reference's block-per-configuration design (GRiDCodeGenerator.py:72-83,
+algorithms/_forward_dynamics_gradient.py:7-57)."""
+import numpy as np
+import pytest
+
+from conftest import make_inputs, relerr
+from gridcodegenerator_amd.emit import cores
+from gridcodegenerator_amd.emit.model import RobotSpec
+
+
+def emulate_block(spec, builder, groups, q, qd, u):
+    """Interpret the cores of one block on the CPU: the exchange region is a dict that every core reads and writes; three
+    sweeps reach the fixed point (Minv and c are published first, then qdd by the producer)."""
+    n, K = spec.n, q.shape[0]
+    slots = cores.CoopSlots(spec)
+    traces = [builder(role, cols, slots) for (role, cols) in groups]
+    base = {"gravity": np.full(K, 9.81)}
+    for j in range(n):
+        base["in.q(%d)" % j] = q[:, j]; base["in.qd(%d)" % j] = qd[:, j]; base["in.u(%d)" % j] = u[:, j]
+    xch = {"in.xch_get(%d)" % s: np.zeros(K) for s in range(slots.count)}
+    got = np.zeros((K, 2 * n * n))
+    for sweep in range(3):
+        # c and qdd share slots: replay the block in program order -- phase 1 publishes (Minv | c), phase 2 (producer) qdd
+        new = {}
+        for tr, (role, cols) in zip(traces, groups):
+            inp = dict(base); inp.update(xch)
+            outs = tr.evaluate(inp)
+            seen_barriers = 0
+            for (dst, _), o in zip(tr.outputs, outs):
+                if dst == "barrier":
+                    seen_barriers += 1
+                elif isinstance(dst, str) and dst.startswith("xch:"):
+                    if (sweep == 0 and seen_barriers == 0) or (sweep >= 1 and seen_barriers == 1):
+                        new["in.xch_get(%s)" % dst[4:]] = np.broadcast_to(o, (K,)).astype(np.float32).astype(np.float64)
+                elif not isinstance(dst, str) and sweep == 2:
+                    L = n * len(cols)
+                    half, rem = divmod(int(dst), L)
+                    ci, r = divmod(rem, n)
+                    got[:, half * n * n + n * cols[ci] + r] = o
+        xch.update(new)
+    return got, traces
+
+
+@pytest.mark.parametrize("schedule", ["fused", "recompute"])
+def test_coop_cores_match_oracle(robot_name, schedule, robots, tables):
+    from oracle import rbd_oracle as O
+    spec = RobotSpec(robots(robot_name))
+    n, K = spec.n, 4
+    if schedule == "fused" and n > 12:
+        pytest.skip("large robots use the recomputing schedule")
+    q, qd, u = (a.astype(np.float64) for a in make_inputs(n, K, 19))
+    ref = O.fd_grad(tables(robot_name), q, qd, u)
+    ref = np.concatenate([O.flat_colmajor(ref[:, :, :n]), O.flat_colmajor(ref[:, :, n:])], axis=1)
+    b = [0, n // 4, n // 2, 3 * n // 4, n]
+    groups = [("producer", list(range(b[3], b[4]))), ("consumer_c", list(range(b[0], b[1]))), ("consumer", list(range(b[1], b[2]))),
+              ("consumer", list(range(b[2], b[3])))]
+    if schedule == "fused":
+        builder = lambda role, cols, sl: cores.core_forward_dynamics_gradient_coop(spec, role, cols, sl)
+    else:
+        builder = lambda role, cols, sl: cores.core_gradient_recompute(spec, "fd", cols=cols, coop=(role, sl))
+    got, traces = emulate_block(spec, builder, groups, q, qd, u)
+    # the exchange region holds fp32: Minv, c and qdd are rounded once on their way through it
+    assert relerr(got, ref)[0] < 5e-6
+    for tr, (role, cols) in zip(traces, groups):
+        dsts = [d for (d, _) in tr.outputs]
+        assert dsts.count("barrier") == 2                      # every wave executes the same two block barriers
+        puts = [d for d in dsts if isinstance(d, str) and d.startswith("xch:")]
+        assert (len(puts) > n) == (role == "producer")
+    # the producer is the only core that contains the Minv recursion
+    rcp = [sum(v for k, v in tr.op_counts().items() if k.startswith("rcp")) for tr in traces]
+    assert rcp[0] > 0 and rcp[1:] == [0, 0, 0]
+
+
+def test_generator_emits_coop_kernel(tmp_path, monkeypatch, robots):
+    from gridcodegenerator_amd import GRiDCodeGenerator
+    monkeypatch.chdir(tmp_path)
+    gen = GRiDCodeGenerator(robots("mixed5"))
+    gen.gen_all_code()
+    code = gen.code_str
+    assert "void forward_dynamics_gradient_kernel_coop(T *d_df_du, const T *d_q_qd_u, const int stride_q_qd_u" in code
+    assert "const int FD_DU_COOP_WAVES = 4;" in code and "in.barrier();" in code and "in.xch_put(" in code and "in.xch_get(" in code
+    roles = [r for (r, c) in gen.coop_stats["groups"]]
+    assert roles == ["producer", "consumer_c", "consumer", "consumer"]
+    cols = sorted(c for (_, cs) in gen.coop_stats["groups"] for c in cs)
+    assert cols == list(range(5))
+    assert gen.coop_stats["lds_bytes"] <= 160 * 1024
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("robot", ["iiwa7", "mixed5", "atlas30"])
+def test_coop_kernel_on_gpu(robot, tables):
+    """Through the C ABI: the tile-cooperative kernel against the oracle and against the single-wave kernel, ragged batches,
+    few blocks (grid-stride over tiles), rows past the batch untouched."""
+    import torch
+    from gridcodegenerator_amd import host
+    from test_gpu_parity import TOL, oracle_all, pack
+    host.build_library(robot, host.DEFAULT_PRECISION)
+    T = tables(robot)
+    with host.GridHandle(robot, device=0, precision=host.DEFAULT_PRECISION) as h:
+        assert h.coop_available(host.ALG_FD_DU)
+        n = h.n
+        for K in (1, 70, 333):
+            q, qd, u = make_inputs(n, K, 90 + K)
+            ref = oracle_all(T, q, qd, u)
+            d_in = torch.from_numpy(pack(q, qd, u)).cuda()
+            h.set_coop(host.ALG_FD_DU, 1); h.set_split(host.ALG_FD_DU, 1)
+            plain = torch.zeros((K, 2 * n * n), dtype=torch.float32, device="cuda")
+            h.forward_dynamics_gradient_device(plain.data_ptr(), d_in.data_ptr(), 3 * n, K)
+            h.synchronize()
+            h.set_coop(host.ALG_FD_DU, 2); h.set_split(host.ALG_FD_DU, 0)
+            assert h.get_coop(host.ALG_FD_DU, K)
+            outs = []
+            for blocks in (0, 1, 2):
+                out = torch.full((K + 2, 2 * n * n), 4.25, dtype=torch.float32, device="cuda")
+                h.forward_dynamics_gradient_device(out.data_ptr(), d_in.data_ptr(), 3 * n, K, blocks=blocks)
+                h.synchronize()
+                o = out.cpu().numpy()
+                assert np.all(o[K:] == 4.25)
+                outs.append(o[:K])
+            assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+            err = relerr(outs[0], ref["df_du"])[0]
+            assert err < TOL[robot]["df_du"], (robot, K, err)
+            assert relerr(outs[0], plain.cpu().numpy().astype(np.float64))[0] < 2 * TOL[robot]["df_du"]
+        h.set_coop(host.ALG_FD_DU, 0)
+
+
+@pytest.mark.gpu
+def test_coop_kernel_full_size_iiwa7_16384(tables):
+    """BASELINE.json configs[2] through the tile-cooperative kernel: spread sample against the oracle + permutation invariance."""
+    import torch
+    from gridcodegenerator_amd import host
+    from test_gpu_parity import TOL, oracle_all, pack
+    with host.GridHandle("iiwa7", device=0, precision=host.DEFAULT_PRECISION) as h:
+        n, K = h.n, 16384
+        h.set_coop(host.ALG_FD_DU, 2)
+        q, qd, u = make_inputs(n, K, 3)
+        x = pack(q, qd, u)
+        d_in = torch.from_numpy(x).cuda()
+        d_out = torch.empty((K, 2 * n * n), dtype=torch.float32, device="cuda")
+        h.forward_dynamics_gradient_device(d_out.data_ptr(), d_in.data_ptr(), 3 * n, K)
+        h.synchronize()
+        df = d_out.cpu().numpy()
+        rows = np.unique(np.concatenate([np.arange(64), np.linspace(0, K - 1, 192).astype(int), np.arange(K - 64, K)]))
+        ref = oracle_all(tables("iiwa7"), q[rows], qd[rows], u[rows])
+        assert relerr(df[rows], ref["df_du"])[0] < TOL["iiwa7"]["df_du"]
+        perm = np.random.default_rng(4).permutation(K)
+        d_in_p = torch.from_numpy(np.ascontiguousarray(x[perm])).cuda()
+        d_out_p = torch.empty_like(d_out)
+        h.forward_dynamics_gradient_device(d_out_p.data_ptr(), d_in_p.data_ptr(), 3 * n, K)
+        h.synchronize()
+        assert np.array_equal(d_out_p.cpu().numpy(), df[perm])

@@ -98,3 +98,120 @@ def test_unsupported_input():
         urdf.load_urdf(CHAIN.replace('type="continuous"', 'type="floating"') % dict(sign=""))
     with pytest.raises(ValueError):
         urdf.load_urdf("<notrobot/>")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a URDF text written by hand in the style of a vendor description (NOT by this package's exporter), checked against an
+# independent forward-kinematics / energy computation done right here from the XML
+# ---------------------------------------------------------------------------------------------------------------------
+def _rot(axis, angle):
+    axis = np.asarray(axis, dtype=np.float64)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return np.eye(3) + np.sin(angle) * K + (1 - np.cos(angle)) * K @ K
+
+
+def _rpy(r, p, y):
+    return _rot((0, 0, 1), y) @ _rot((0, 1, 0), p) @ _rot((1, 0, 0), r)
+
+
+class _PlainFK:
+    """World poses of every link of a URDF for given joint angles -- straight from the XML, no spatial algebra."""
+
+    def __init__(self, path):
+        import xml.etree.ElementTree as ET
+        root = ET.parse(path).getroot()
+        num = lambda e, key, d: np.array([float(v) for v in (e.get(key) if e is not None and e.get(key) else d).split()])
+        self.links = {}
+        for l in root.findall("link"):
+            i = l.find("inertial")
+            if i is None:
+                continue
+            o, inr = i.find("origin"), i.find("inertia")
+            I = np.array([[float(inr.get("ixx")), float(inr.get("ixy")), float(inr.get("ixz"))],
+                          [float(inr.get("ixy")), float(inr.get("iyy")), float(inr.get("iyz"))],
+                          [float(inr.get("ixz")), float(inr.get("iyz")), float(inr.get("izz"))]])
+            self.links[l.get("name")] = (float(i.find("mass").get("value")), num(o, "xyz", "0 0 0"), _rpy(*num(o, "rpy", "0 0 0")), I)
+        self.joints = []
+        for j in root.findall("joint"):
+            o, a = j.find("origin"), j.find("axis")
+            self.joints.append(dict(name=j.get("name"), type=j.get("type"), parent=j.find("parent").get("link"), child=j.find("child").get("link"),
+                                    xyz=num(o, "xyz", "0 0 0"), R=_rpy(*num(o, "rpy", "0 0 0")), axis=num(a, "xyz", "1 0 0")))
+        self.moving = [j["name"] for j in self.joints if j["type"] != "fixed"]
+
+    def poses(self, q):
+        q = dict(zip(self.moving, q))
+        pose = {"world": (np.eye(3), np.zeros(3))}
+        pending = list(self.joints)
+        while pending:
+            for j in list(pending):
+                if j["parent"] in pose:
+                    Rp, pp = pose[j["parent"]]
+                    R = Rp @ j["R"]
+                    if j["type"] != "fixed":
+                        R = R @ _rot(j["axis"], q[j["name"]])
+                    pose[j["child"]] = (R, Rp @ j["xyz"] + pp)
+                    pending.remove(j)
+        return pose
+
+    def potential(self, q, g=9.81):
+        pose = self.poses(q)
+        return sum(m * g * (pose[name][0] @ c + pose[name][1])[2] for name, (m, c, Ri, I) in self.links.items() if name != "link_0")
+
+    def kinetic(self, q, qd, eps=1e-6):
+        plus, minus = self.poses(q + eps * qd), self.poses(q - eps * qd)
+        now = self.poses(q)
+        T = 0.0
+        for name, (m, c, Ri, I) in self.links.items():
+            v = ((plus[name][0] @ c + plus[name][1]) - (minus[name][0] @ c + minus[name][1])) / (2 * eps)
+            W = (plus[name][0] - minus[name][0]) / (2 * eps) @ now[name][0].T
+            w = np.array([W[2, 1], W[0, 2], W[1, 0]])
+            Iw = now[name][0] @ Ri @ I @ Ri.T @ now[name][0].T
+            T += 0.5 * m * v @ v + 0.5 * w @ Iw @ w
+        return T
+
+
+def test_hand_written_urdf_against_independent_energies():
+    """tests/fixtures/lbr_iiwa14_like.urdf (world weld, alternating frames, a -z joint axis, rotated inertial frames, a
+    flange + tool welded on): the loaded robot's gravity torques equal dU/dq and its mass matrix equals the Hessian of the
+    kinetic energy, both computed from the XML by plain forward kinematics."""
+    from urdf_fixture import FIXTURE
+    robot = urdf.load_urdf(FIXTURE)
+    fk = _PlainFK(FIXTURE)
+    n = robot.get_num_joints()
+    assert n == 7 and fk.moving == [robot.get_joint_by_id(j).get_name() for j in range(n)]
+    T = O.RobotTables(robot)
+    rng = np.random.default_rng(4)
+    for _ in range(3):
+        q = rng.uniform(-2.0, 2.0, n)
+        tau_g = O.rnea(T, q[None], np.zeros((1, n)), np.zeros((1, n)))[0][0]
+        dU = np.array([(fk.potential(q + 1e-6 * e) - fk.potential(q - 1e-6 * e)) / 2e-6 for e in np.eye(n)])
+        assert np.abs(tau_g - dU).max() < 1e-6 * max(1.0, np.abs(dU).max())
+        M = np.linalg.inv(O.minv(T, q[None], True)[0])
+        Tk = lambda qd: fk.kinetic(q, qd)
+        M_fd = np.array([[Tk(ei + ej) - Tk(ei) - Tk(ej) if i != j else 2 * Tk(ei) for j, ej in enumerate(np.eye(n))] for i, ei in enumerate(np.eye(n))])
+        assert np.abs(M - M_fd).max() < 2e-6 * np.abs(M).max()
+    assert [robot.get_damping_by_id(j) for j in range(n)] == [0.5, 0.5, 0.5, 0.5, 0.3, 0.3, 0.1]
+
+
+@pytest.mark.gpu
+def test_hand_written_urdf_on_gpu():
+    """URDF file -> loader -> generator -> hipcc -> C ABI -> GPU, all five algorithms against the oracle on the same robot."""
+    from urdf_fixture import register
+    from gridcodegenerator_amd import host
+    from test_gpu_parity import TOL, oracle_all, pack
+    name = register()
+    host.build_library(name, host.DEFAULT_PRECISION)
+    robot = host.get_robot(name)
+    T = O.RobotTables(robot)
+    tol = TOL["iiwa7"]                                   # same size and mass range as the built-in 7-joint arm
+    with host.GridHandle(name, device=0, precision=host.DEFAULT_PRECISION) as h:
+        n, K = h.n, 333
+        q, qd, u = make_inputs(n, K, 81)
+        ref = oracle_all(T, q, qd, u)
+        x = pack(q, qd, u)
+        from conftest import relerr
+        assert relerr(h.inverse_dynamics(x), ref["c"])[0] < tol["c"]
+        assert relerr(h.direct_minv(x), ref["Minv"])[0] < tol["Minv"]
+        assert relerr(h.forward_dynamics(x), ref["qdd"])[0] < tol["qdd"]
+        assert relerr(h.inverse_dynamics_gradient(x), ref["dc_du_noqdd"])[0] < tol["dc_du"]
+        assert relerr(h.forward_dynamics_gradient(x), ref["df_du"])[0] < tol["df_du"]
