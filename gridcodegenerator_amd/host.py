@@ -149,8 +149,8 @@ def kernel_dependency_hashes(header_text, kernel_names):
 # Build-time resource guard.  The round-1 GPU failures (a memory fault, silently wrong numbers, hangs: DESIGN.md section 9) all came
 # from kernels that hipcc could only build with kilobytes of scratch per lane and hundreds of SGPR spills; nothing that heavy is
 # allowed into a library any more unless the caller explicitly builds an unverified variant.
-MAX_SCRATCH_BYTES_PER_LANE = 1024
-MAX_SGPR_SPILLS = 128
+MAX_SCRATCH_BYTES_PER_LANE = 1536      # round 1's failing builds: 1.7 KB + 183 SGPR spills (register-capped), 2.5-4.7 KB (fused n > 12), fp64
+MAX_SGPR_SPILLS = 64                   # what ships now: <= 1.35 KB (the kernels that keep all of Minv alive) and <= 22 SGPR spills
 
 
 def parse_kernel_resources(log_text):
@@ -364,6 +364,39 @@ def build_api_harness(robot_name, precision="fp32", force=False):
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if proc.returncode != 0:
         raise GridLibraryError("hipcc failed for the API-surface harness of %s:\n%s" % (robot_name, proc.stdout[-4000:]))
+    os.replace(out + ".tmp", out)
+    with open(out + ".key", "w") as fh:
+        fh.write(key)
+    return out
+
+
+SINGLE_TIMING_SRC = os.path.join(REPO_DIR, "tests", "single_timing_harness.hip")
+
+
+def single_timing_harness_path(robot_name, precision="fp32"):
+    return os.path.join(BUILD_DIR, "single_timing_harness_%s_%s" % (robot_name, precision))
+
+
+def build_single_timing_harness(robot_name, precision="fp32", force=False):
+    """TEST INFRASTRUCTURE: the GRiD-style main() of tests/single_timing_harness.hip (reference mode 1: `Single Call <label>`
+    latency twins) compiled against the robot's header; an executable, prebuilt so that the GPU box only runs it."""
+    build_library(robot_name, precision)
+    p = library_paths(robot_name, precision)
+    out = single_timing_harness_path(robot_name, precision)
+    h = hashlib.sha256()
+    for fn in (p["header"], SINGLE_TIMING_SRC):
+        with open(fn, "rb") as fh:
+            h.update(fh.read())
+    key = h.hexdigest()
+    if not force and os.path.exists(out) and os.path.exists(out + ".key"):
+        with open(out + ".key") as fh:
+            if fh.read().strip() == key:
+                return out
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O1", "-ffp-contract=off", "-std=c++17", "-DGRID_HEADER=\"%s\"" % p["header"],
+           "-DGRID_NS=grid_" + robot_name, SINGLE_TIMING_SRC, "-o", out + ".tmp"]
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if proc.returncode != 0:
+        raise GridLibraryError("hipcc failed for the single-timing harness of %s:\n%s" % (robot_name, proc.stdout[-4000:]))
     os.replace(out + ".tmp", out)
     with open(out + ".key", "w") as fh:
         fh.write(key)

@@ -193,7 +193,7 @@ def test_mixed_precision_header(tmp_path, robots):
     assert "template <> struct grid_compute<float> {typedef float type;};" in code and "const D t" in code
     st = gen.core_stats["forward_dynamics_gradient_core"] if "forward_dynamics_gradient_core" in gen.core_stats else {}
     minv = gen.core_stats["direct_minv_core"]
-    assert minv.get("fma.d", 0) > 0 and minv.get("fma", 0) == 0          # the whole recursion is in double
+    assert minv.get("fma.d", 0) > 10 * minv.get("fma", 0) > 0             # the recursion is in double; only X(q) is formed in float
     rnea = gen.core_stats["inverse_dynamics_core"]
     assert not any(k.endswith(".d") for k in rnea)                        # RNEA stays in float
     from gridcodegenerator_amd.emit.trace import Tracer

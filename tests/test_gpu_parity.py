@@ -407,19 +407,13 @@ def test_minv_times_mass_matrix_on_gpu(handles, torch_cuda):
     assert np.abs(np.einsum("kij,kjl->kil", Mi, M) - np.eye(n)).max() < 5e-4
 
 
-def test_single_timing_twins(torch_cuda, tmp_path):
+def test_single_timing_twins(torch_cuda):
     """The *_single_timing host wrappers / *_kernel_single_timing kernels of the generated header (reference mode 1):
     a GRiD-style main() compiled with hipcc against the iiwa-7 header must leave the same results in the host buffers
     as the mode-0 wrappers and print the reference's `Single Call <label>` lines."""
     import subprocess
     from gridcodegenerator_amd import host
-    host.build_library("iiwa7", host.DEFAULT_PRECISION)
-    header = host.library_paths("iiwa7", host.DEFAULT_PRECISION)["header"]
-    exe = str(tmp_path / "single_timing_harness")
-    here = os.path.dirname(os.path.abspath(__file__))
-    cmd = [host._hipcc(), "--offload-arch=gfx950", "-O1", "-ffp-contract=off", "-std=c++17",
-           "-DGRID_HEADER=\"%s\"" % header, "-DGRID_NS=grid_iiwa7", os.path.join(here, "single_timing_harness.hip"), "-o", exe]
-    subprocess.run(cmd, check=True, timeout=900)
+    exe = host.build_single_timing_harness("iiwa7", host.DEFAULT_PRECISION)      # prebuilt by build(); rebuilt only if stale
     run = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     out = run.stdout
     assert run.returncode == 0 and "ALL MATCH" in out, out
