@@ -1042,12 +1042,22 @@ class AlgorithmEmitMixin:
     COOP_WAVES = 4
 
     def _coop_groups(self, builder, slots):
-        """Column groups of the cooperating waves: contiguous, balanced on (phase-1 work of the wave's role) + (traced cost of
-        its columns).  The producer (Minv) takes the LAST group -- late columns are the cheapest -- so that its longer
-        phase 1 is paid back by a shorter phase 2.  Returns [(role, cols)], producer first."""
+        """Column groups of the cooperating waves: contiguous, balanced on the work each wave has left after the second barrier
+        (the producer must recompute RNEA there, the consumers only its qdd-dependent part).  The producer takes the LAST
+        group (late columns are the cheapest).  Returns [(role, cols)], producer first."""
         n, W = self.spec.n, self.COOP_WAVES
         roles = ["producer", "consumer_c"] + ["consumer"] * (W - 2)
-        ops = lambda role, cols: cores._arith_ops(builder(role, cols, slots))
+        def ops(role, cols):
+            # what decides the block's time is the work AFTER the second barrier: every wave leaves it at the same moment (when the
+            # producer has published qdd), so the block finishes with the wave that has the most phase-2 instructions
+            # (arithmetic + exchange-region reads issued after the barrier)
+            tr = builder(role, cols, slots)
+            live = tr.live_nodes()
+            barriers = [pos for (dst, _), pos in zip(tr.outputs, tr.out_pos) if dst == "barrier"]
+            start = barriers[-1]
+            arith = ("fma", "mul", "add", "pkfma", "pkmul", "pkadd")
+            return sum(1 for k in range(start, len(tr.nodes)) if live[k] and (tr.nodes[k][0] in arith or (
+                tr.nodes[k][0] == "in" and str(tr.nodes[k][1]).startswith("in.xch_get("))))
         single = {role: [ops(role, [c]) for c in range(n)] for role in ("producer", "consumer")}
         base = {role: min(single[role]) for role in single}
         marg = {role: [x - base[role] for x in single[role]] for role in single}
@@ -1063,7 +1073,34 @@ class AlgorithmEmitMixin:
             worst = max([cost("producer", *parts[-1])] + [cost("consumer", *p) for p in parts[:-1]])
             if best is None or worst < best[0]:
                 best = (worst, parts)
-        parts = best[1]
+        parts = list(best[1])
+        # the additive model is rough for large robots (what a column costs depends on its neighbours): hill-climb on EXACT costs
+        role_of = lambda i: "producer" if i == W - 1 else "consumer"
+        exact = {}
+
+        def cost_exact(i, pr):
+            key = (role_of(i), pr)
+            if key not in exact:
+                exact[key] = ops(role_of(i), list(range(*pr)))
+            return exact[key]
+        for _ in range(8 if n > 8 else 0):
+            costs = [cost_exact(i, parts[i]) for i in range(W)]
+            worst = max(range(W), key=lambda i: costs[i])
+            improved = None
+            for nb in (worst - 1, worst + 1):
+                if nb < 0 or nb >= W or parts[worst][1] - parts[worst][0] < 2:
+                    continue
+                trial = list(parts)
+                if nb < worst:      # give the first column of `worst` to the group before it
+                    trial[nb] = (parts[nb][0], parts[nb][1] + 1); trial[worst] = (parts[worst][0] + 1, parts[worst][1])
+                else:               # give the last column to the group after it
+                    trial[worst] = (parts[worst][0], parts[worst][1] - 1); trial[nb] = (parts[nb][0] - 1, parts[nb][1])
+                new_max = max(cost_exact(i, trial[i]) for i in range(W))
+                if new_max < costs[worst] and (improved is None or new_max < improved[0]):
+                    improved = (new_max, trial)
+            if improved is None:
+                break
+            parts = improved[1]
         groups = [("producer", list(range(*parts[-1])))]
         for role, pr in zip(roles[1:], parts[:-1]):
             groups.append((role, list(range(*pr))))

@@ -320,20 +320,29 @@ def rnea_grad(tr, spec, X, I, qd, v, a, f, gravity):
     return dc
 
 
-def sym_minv_times_columns(tr, spec, entry, dc_lo, dc_hi):
+def sym_minv_times_columns(tr, spec, entry, dc_lo, dc_hi, block=16):
     """-Minv_sym @ [dc_lo | dc_hi] for ONE gradient column with every upper-triangle entry of Minv fetched once:
     entry(r, k) (r <= k) -> traced value or None (structural zero); dc_lo / dc_hi: {row: value} of the non-zero rows.
-    4 multiply-adds per fetched entry (both halves, both triangles) -- for cores that re-read Minv from LDS per column."""
+    Up to 4 multiply-adds per fetched entry (both halves, both triangles) -- for cores that re-read Minv from LDS per column.
+    The fetches are software-pipelined in trace order: the entries of block b + 1 are requested before the multiply-adds of
+    block b (creation-order emission keeps that order), so a lone wavefront does not pay an LDS round trip per entry."""
     n = spec.n
     acc_lo = [tr.zero() for _ in range(n)]
     acc_hi = [tr.zero() for _ in range(n)]
+    need = []
     for k in range(n):
         for r in range(k + 1):
             need_rk = k in dc_lo             # contributes to row r through dc[k]
             need_kr = (r != k) and (r in dc_lo)
-            if not (need_rk or need_kr):
-                continue
-            m = entry(r, k)
+            if need_rk or need_kr:
+                need.append((r, k, need_rk, need_kr))
+    blocks = [need[i:i + block] for i in range(0, len(need), block)]
+    fetch = lambda blk: [entry(r, k) for (r, k, _, _) in blk]
+    pending = fetch(blocks[0]) if blocks else []
+    for b, blk in enumerate(blocks):
+        vals = pending
+        pending = fetch(blocks[b + 1]) if b + 1 < len(blocks) else []
+        for (r, k, need_rk, need_kr), m in zip(blk, vals):
             if m is None:
                 continue
             if need_rk:

@@ -22,6 +22,9 @@ def _p(a):
 
 
 def _load(robot):
+    import torch  # noqa: F401  (FIRST: torch carries its own HIP runtime; a process that loads /opt/rocm's copy before it -- as this
+    #                harness would -- ends up with two runtimes and torch.cuda.is_available() turns False for the tests that follow)
+    torch.cuda.is_available()
     from gridcodegenerator_amd import host
     path = host.build_api_harness(robot, host.DEFAULT_PRECISION)        # built by build(); rebuilt here only if stale
     lib = ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL)
@@ -65,7 +68,9 @@ def test_api_surface_on_gpu(robot_name, tables):
     qdd32 = np.ascontiguousarray(parts["qdd"].astype(np.float32))
     Minv_ref = O.flat_colmajor(np.triu(parts["Minv"]))
     Minv32 = np.ascontiguousarray(Minv_ref.astype(np.float32))
-    qdd_in = qdd32.astype(np.float64)
+    # ID with qdd: NOT the forward-dynamics result (ID(q, qd, FD(q, qd, u)) = u by cancellation, which measures nothing)
+    qdd_alt32 = np.ascontiguousarray((0.7 * u).astype(np.float32))
+    qdd_in = qdd_alt32.astype(np.float64)
     expect = {
         "id": (parts["c"], "c"), "id_qdd": (O.rnea(T, q64, qd64, qdd_in)[0], "c_qdd"), "minv": (Minv_ref, "Minv"), "fd": (parts["qdd"], "qdd"),
         "idgrad": (gflat(O.rnea_grad(T, q64, qd64, None)), "dc_du"), "idgrad_qdd": (gflat(O.rnea_grad(T, q64, qd64, qdd_in)), "dc_du"),
@@ -74,7 +79,8 @@ def test_api_surface_on_gpu(robot_name, tables):
 
     def run(name, count):
         out = np.full((K, count), np.nan, dtype=np.float32)
-        rc = lib.as_run(name.encode(), _p(x), _p(qdd32), _p(Minv32), K, ctypes.c_float(9.81), _p(out))
+        qdd_arg = qdd32 if name.startswith("fdgrad") else qdd_alt32         # the qdd+Minv variant needs the matching qdd
+        rc = lib.as_run(name.encode(), _p(x), _p(qdd_arg), _p(Minv32), K, ctypes.c_float(9.81), _p(out))
         assert rc == 0, (name, rc, lib.as_last_error().decode())
         return out
 

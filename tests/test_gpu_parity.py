@@ -20,11 +20,16 @@ pytestmark = pytest.mark.gpu
 _T = lambda c, c_qdd, Minv, qdd, dc_du, df_du, df_du_qdd_minv: dict(c=c, c_qdd=c_qdd, Minv=Minv, qdd=qdd, dc_du=dc_du, df_du=df_du,
                                                                        df_du_qdd_minv=df_du_qdd_minv)
 TOL_BY_PRECISION = {
-    "fp32": {"iiwa7": _T(2e-6, 2e-6, 5e-6, 3e-5, 5e-6, 3e-5, 3e-5), "atlas30": _T(2e-6, 2e-6, 5e-6, 3e-5, 5e-6, 3e-5, 3e-5),
-             "mixed5": _T(2e-6, 2e-6, 5e-6, 3e-5, 5e-6, 3e-5, 3e-5)},
-    "mixed": {"iiwa7": _T(2e-6, 2e-6, 5e-6, 3e-5, 5e-6, 3e-5, 3e-5), "atlas30": _T(2e-6, 2e-6, 5e-6, 3e-5, 5e-6, 3e-5, 3e-5),
-              "mixed5": _T(2e-6, 2e-6, 5e-6, 3e-5, 5e-6, 3e-5, 3e-5)},
+    # measured (profiles/r02/precision_report_fp32.txt, max over the K = 201 and K = 2048 batches):
+    #   iiwa7    c 2.8e-7  Minv 6.6e-8  qdd 9.1e-8  dc_du 2.3e-7  df_du 7.2e-7  df_du(qdd, Minv given) 5.5e-7
+    #   atlas30  c 2.6e-7  Minv 1.3e-7  qdd 2.7e-7  dc_du 3.5e-7  df_du 5.7e-6  df_du(qdd, Minv given) 5.7e-7
+    #   mixed5   c 3.8e-7  Minv 4.2e-8  qdd 1.8e-7  dc_du 1.6e-7  df_du 8.3e-7  df_du(qdd, Minv given) 8.3e-7
+    "fp32": {"iiwa7": _T(8e-7, 1e-6, 2e-7, 3e-7, 7e-7, 2e-6, 1.6e-6), "atlas30": _T(8e-7, 1e-6, 4e-7, 8e-7, 1e-6, 1.7e-5, 1.7e-6),
+             "mixed5": _T(1e-6, 1.2e-6, 1.3e-7, 5e-7, 5e-7, 2.5e-6, 2.5e-6)},
+    # measured (precision_report_mixed.txt): iiwa7 Minv 6.2e-8 qdd 6.6e-8 df_du 5.2e-7; mixed5 Minv 3.4e-8 qdd 1.8e-7 df_du 8.3e-7
+    "mixed": {"iiwa7": _T(8e-7, 1e-6, 2e-7, 2e-7, 7e-7, 1.5e-6, 1.6e-6), "mixed5": _T(1e-6, 1.2e-6, 1e-7, 5e-7, 5e-7, 2.5e-6, 2.5e-6)},
 }
+NORTH_STAR = 1e-6       # "fp32 torques/accelerations within 1e-6 rel"
 
 
 def _default_precision():
@@ -84,10 +89,10 @@ def test_all_algorithms_host_api(robot_name, handles, tables):
     q, qd, u = make_inputs(n, K, 31)
     ref = oracle_all(tables(robot_name), q, qd, u)
     x = pack(q, qd, u)
-    assert relerr(h.inverse_dynamics(x, gravity=G), ref["c"])[0] < tol["c"]
+    assert relerr(h.inverse_dynamics(x, gravity=G), ref["c"])[0] < min(tol["c"], NORTH_STAR)
     assert relerr(h.direct_minv(x), ref["Minv"])[0] < tol["Minv"]
     qdd = h.forward_dynamics(x, gravity=G)
-    assert relerr(qdd, ref["qdd"])[0] < tol["qdd"]
+    assert relerr(qdd, ref["qdd"])[0] < min(tol["qdd"], NORTH_STAR)
     assert relerr(h.inverse_dynamics_gradient(x, gravity=G), ref["dc_du_noqdd"])[0] < tol["dc_du"]
     qdd_ref32 = ref["qdd"].astype(np.float32)
     from oracle import rbd_oracle as O
@@ -95,7 +100,8 @@ def test_all_algorithms_host_api(robot_name, handles, tables):
     dc = O.rnea_grad(T, q.astype(np.float64), qd.astype(np.float64), qdd_ref32.astype(np.float64))
     dc = np.concatenate([O.flat_colmajor(dc[:, :, :n]), O.flat_colmajor(dc[:, :, n:])], axis=1)
     assert relerr(h.inverse_dynamics_gradient(x, qdd=qdd_ref32, gravity=G), dc)[0] < tol["dc_du"]
-    assert relerr(h.inverse_dynamics(x, qdd=qdd_ref32, gravity=G), O.rnea(T, q.astype(np.float64), qd.astype(np.float64), qdd_ref32.astype(np.float64))[0])[0] < tol["c_qdd"]
+    qdd_alt = np.ascontiguousarray((0.7 * u).astype(np.float32))      # (not the FD result: ID(FD(u)) = u by cancellation)
+    assert relerr(h.inverse_dynamics(x, qdd=qdd_alt, gravity=G), O.rnea(T, q.astype(np.float64), qd.astype(np.float64), qdd_alt.astype(np.float64))[0])[0] < tol["c_qdd"]
     assert relerr(h.forward_dynamics_gradient(x, gravity=G), ref["df_du"])[0] < tol["df_du"]
     # USE_QDD_MINV_FLAG variant: qdd and (upper triangular) Minv supplied by the caller
     Minv32 = ref["Minv"].astype(np.float32)
@@ -360,12 +366,20 @@ def test_full_size_atlas30_65536(handles, tables, torch_cuda):
     _full_size_properties(handles("atlas30"), tables("atlas30"), 65536, 4, torch_cuda, check_rows=64, check_id_grad=True)
 
 
-def test_full_size_atlas30_16384_column_groups(handles, tables, torch_cuda):
-    """north_star target "Atlas-30 at batch 16k": served by the x4 column-group kernels (one wave per SIMD)."""
+def test_full_size_atlas30_16384(handles, tables, torch_cuda):
+    """north_star target "Atlas-30 at batch 16k": served by the tile-cooperative kernel (automatic choice for large robots from
+    192 tiles on), and -- forced -- by the x4 column-group kernels it replaced there; the two agree to round-off."""
     from gridcodegenerator_amd import host
     h = handles("atlas30")
-    assert h.get_split(host.ALG_FD_DU, 16384) == 4
-    _full_size_properties(h, tables("atlas30"), 16384, 6, torch_cuda, check_rows=64)
+    assert h.get_coop(host.ALG_FD_DU, 16384) and not h.get_coop(host.ALG_FD_DU, 4096)
+    df_coop = _full_size_properties(h, tables("atlas30"), 16384, 6, torch_cuda, check_rows=64)
+    h.set_coop(host.ALG_FD_DU, 1)
+    try:
+        assert h.get_split(host.ALG_FD_DU, 16384) == 4
+        df_split = _full_size_properties(h, tables("atlas30"), 16384, 6, torch_cuda, check_rows=64)
+    finally:
+        h.set_coop(host.ALG_FD_DU, 0)
+    assert relerr(df_coop, df_split.astype(np.float64))[0] < 2 * TOL["atlas30"]["df_du"]
 
 
 def test_shard_size_atlas30_131072(handles, tables, torch_cuda):
