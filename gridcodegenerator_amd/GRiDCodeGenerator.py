@@ -50,7 +50,10 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin, Verific
         split_sets=False,       # column groups of the S >= 3 splits as arbitrary column sets (12.05 vs 11.46 us at K=16384); mixed5 tests it
         fence_stride=1,         # fence after every N-th store instead of every store (12-15 % slower, spills)
         dot_ways=1,             # dot products over w interleaved accumulators (0-4 % slower)
-        split_cap=(2,),         # which split factors are register-capped to two waves per SIMD (small robots only)
+        split_cap=(2,),         # which split factors are register-capped to two waves per SIMD (small robots only); capping the finer
+                                # splits too was re-measured on the spill-free round-2 kernels: x7 capped 14.8 vs x4 11.1 us at K=16384
+        coop_hoist=False,       # tile-cooperative cores of small robots: force everything that does not depend on qdd in front of
+                                # the first barrier (and let the producer go without columns): 12.9 vs 12.1 us at K=16384
     )
 
     def __init__(self, robotObj, DEBUG_MODE=False, NEED_PRINT_MAT=False, USE_DYNAMIC_SHARED_MEM=True,
@@ -114,6 +117,7 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin, Verific
         self.fence_stride = int(exp["fence_stride"])
         self.dot_ways = int(exp["dot_ways"])
         self.split_cap = tuple(int(x) for x in exp["split_cap"])
+        self.coop_hoist = bool(exp["coop_hoist"])
         self.kernel_instances = []
         self.split_stats = {}
         self.emit_inner_api = bool(emit_inner_api)

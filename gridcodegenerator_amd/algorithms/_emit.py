@@ -1041,6 +1041,47 @@ class AlgorithmEmitMixin:
     # ------------------------------------------------------------------------------------------
     COOP_WAVES = 4
 
+    def _coop_groups_fused(self, builder, slots):
+        """Column groups for the fused (small-robot) cooperative cores, chosen on a timeline model of the block:
+
+            B1 = max(Minv of the producer, qdd-independent work of each consumer)      (coop_phase_costs()[0]; consumers hoist it)
+            B2 = B1 + the producer's qdd product
+            end = B2 + max over waves of what is left (consumers: the qdd-dependent part; producer: all of its columns' work)
+
+        The producer takes a (possibly empty) suffix of the columns, the consumers contiguous groups of the rest; exhaustive over
+        the few candidates, every candidate traced exactly.  Returns [(role, cols)], producer first."""
+        import itertools
+        n, W = self.spec.n, self.COOP_WAVES
+        memo = {}
+
+        def costs(role, cols):
+            key = ("producer" if role == "producer" else "consumer", tuple(cols))
+            if key not in memo:
+                memo[key] = cores.coop_phase_costs(builder(role, list(cols), slots))
+            return memo[key]
+        p1_0, p2_0 = costs("producer", ())
+        best = None
+        for kp in range(0, max(1, n - (W - 1)) + 1):
+            pcols = tuple(range(n - kp, n))
+            rest = n - kp
+            if rest < W - 1:
+                continue
+            pp1, pp2 = costs("producer", pcols)
+            left_prod = (pp1 - p1_0) + (pp2 - p2_0)
+            for cuts in itertools.combinations(range(1, rest), W - 2):
+                bounds = (0,) + cuts + (rest,)
+                groups = [tuple(range(bounds[i], bounds[i + 1])) for i in range(W - 1)]
+                cc = [costs("consumer", gcols) for gcols in groups]
+                end = max([p1_0] + [c[0] for c in cc]) + p2_0 + max([left_prod] + [c[1] for c in cc])
+                if best is None or end < best[0]:
+                    best = (end, pcols, groups)
+        end, pcols, groups = best
+        self.coop_model_end = end
+        out = [("producer", list(pcols))]
+        for i, gcols in enumerate(groups):
+            out.append(("consumer_c" if i == 0 else "consumer", list(gcols)))
+        return out
+
     def _coop_groups(self, builder, slots):
         """Column groups of the cooperating waves: contiguous, balanced on the work each wave has left after the second barrier
         (the producer must recompute RNEA there, the consumers only its qdd-dependent part).  The producer takes the LAST
@@ -1123,8 +1164,8 @@ class AlgorithmEmitMixin:
         if rec:
             builder = lambda role, cols, sl: cores.core_gradient_recompute(self.spec, "fd", cols=cols, coop=(role, sl))
         else:
-            builder = lambda role, cols, sl: cores.core_forward_dynamics_gradient_coop(self.spec, role, cols, sl)
-        groups = self._coop_groups(builder, slots)
+            builder = lambda role, cols, sl: cores.core_forward_dynamics_gradient_coop(self.spec, role, cols, sl, hoist=self.coop_hoist)
+        groups = self._coop_groups_fused(builder, slots) if (self.coop_hoist and not rec) else self._coop_groups(builder, slots)
         n_out = self.io_layout["FD_DU"]["n_out"]
         piece = min(32, max(16, n))                  # inputs staged in small pieces: small per-wave staging regions (Atlas-30:
                                                      # 4 x 7.5 KB + 495 exchange slots x 256 B = 154 KB of the CU's 160 KB)
@@ -1177,6 +1218,13 @@ class AlgorithmEmitMixin:
         self.gen_add_code_line("const grid_in_coop<T> in = {s_q_qd_u, s_q_qd_u + %d, s_q_qd_u + %d, s_xch, it.lane};" % (n, 2 * n))
         self.gen_add_code_line("switch (it.wave_in_block){", True)
         for w, (cname, cols) in enumerate(names):
+            if not cols:        # a producer without gradient columns: Minv and qdd only
+                self.gen_add_code_line("case %d: {" % w, True)
+                self.gen_add_code_line("grid_out_ptr<T> out = {nullptr};     // (this core stores nothing)")
+                self.gen_add_code_line("%s<T,C>(in, out, gravity);" % cname)
+                self.gen_add_code_line("break;")
+                self.gen_add_end_control_flow()
+                continue
             len0 = n * len(cols)
             ch = n if rec else self._chunk_for(len0)
             ch = min(ch, max(piece, n)) if 64 * ch > stage else ch

@@ -154,13 +154,17 @@ def rnea(tr, spec, X, I, qd, qdd, gravity):
 # ------------------------------------------------------------------------------------------------
 # direct Minv
 # ------------------------------------------------------------------------------------------------
-def direct_minv(tr, spec, X, I):
-    """Upper-triangular Minv[j][k] (k >= j) as traced scalars; entries k < j are None."""
+def direct_minv(tr, spec, X, I, between=None, on_final=None):
+    """Upper-triangular Minv[j][k] (k >= j) as traced scalars; entries k < j are None.
+
+    between(): called between the backward and the forward pass.  on_final(j, k, value): called as soon as Minv[j][k] has its
+    final value (row j is final when the forward pass has visited joint j) -- a consumer that uses the entry right there (the
+    tile-cooperative producer publishes it and folds it into qdd) lets it die instead of keeping all n(n+1)/2 alive."""
     with tr.mixed_region():
-        return _direct_minv(tr, spec, X, I)
+        return _direct_minv(tr, spec, X, I, between, on_final)
 
 
-def _direct_minv(tr, spec, X, I):
+def _direct_minv(tr, spec, X, I, between=None, on_final=None):
     n = spec.n
     IA = [[[I[j][r][c] if r <= c else None for c in range(6)] for r in range(6)] for j in range(n)]
     for j in range(n):  # mirror so IA[r][c] is IA[c][r] (symmetric by construction)
@@ -206,6 +210,8 @@ def _direct_minv(tr, spec, X, I):
                 val = tr.dot([(X[j][k][r], Tm[k][c]) for k in range(6)], init=IA[p][r][c])
                 IA[p][r][c] = val
                 IA[p][c][r] = val
+    if between is not None:
+        between()
     Fn = {}      # forward-pass F (the reference overwrites F in place, _test.py:198-200)
     for j in range(n):
         p, s = spec.parent[j], spec.S_ind[j]
@@ -217,14 +223,14 @@ def _direct_minv(tr, spec, X, I):
                     continue
                 corr = Dinv[j] * tr.dot([(UX[r], Fpk[r]) for r in range(6)])
                 Minv[j][k] = (Minv[j][k] if Minv[j][k] is not None else tr.zero()) - corr
-        if not spec.children[j]:
-            for k in range(j, n):
-                if Minv[j][k] is None:
-                    Minv[j][k] = tr.zero()
-            continue
         for k in range(j, n):
             if Minv[j][k] is None:
                 Minv[j][k] = tr.zero()
+            if on_final is not None:
+                on_final(j, k, Minv[j][k])
+        if not spec.children[j]:
+            continue
+        for k in range(j, n):
             Fjk = zeros6(tr)
             Fjk[s] = Minv[j][k]
             if p != -1 and (p, k) in Fn:

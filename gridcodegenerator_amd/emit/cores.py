@@ -164,20 +164,35 @@ COOP_ROLES = ("producer", "consumer_c", "consumer")
 def _coop_prologue(tr, spec, slots, role, X, I, qd, u, g):
     """Phases 1 and 2 of a tile-cooperative core; returns qdd (read from the exchange region by every wave).
 
-    producer:  Minv (in double when the build is mixed-precision) -> exchange region | barrier | c from the exchange region,
-               qdd = Minv (u - c) from the Minv it still holds in registers (so the cond(M)-amplified product sees the
-               unrounded Minv) -> exchange region | barrier
+    producer:  backward pass of the Minv recursion | barrier | c from the exchange region; forward pass: every entry of Minv is
+               published as it becomes final and folded into qdd = Minv (u - c) right there (in double when the build is
+               mixed-precision, so the cond(M)-amplified product sees the unrounded Minv) -> qdd to the exchange region | barrier
     consumers: RNEA at qdd = 0 while the producer is busy; one of them publishes c | barrier | barrier"""
     n = spec.n
     if role == "producer":
-        Minv = alg.direct_minv(tr, spec, X, I)
-        for (r, k), slot in slots.minv.items():
-            tr.xch_put(slot, Minv[r][k])
-        tr.barrier()
-        c = [tr.xch_get(slots.c[j]) for j in range(n)]
-        qdd = alg.fd_finish(tr, spec, Minv, u, c)
+        # Minv entries are published -- and folded into qdd = Minv_sym (u - c) -- the moment they are final, so they never all
+        # live at once (465 values for Atlas-30); c is needed from the forward pass on, so the first barrier sits between the
+        # two passes of the recursion (the consumers have long finished RNEA by then)
+        state = {}
+
+        def between():
+            tr.barrier()
+            with tr.mixed_region():
+                state["umc"] = [u[j] - tr.xch_get(slots.c[j]) for j in range(n)]
+                state["acc"] = [tr.zero() for _ in range(n)]
+
+        def on_final(j, k, m):
+            slot = slots.minv.get((j, k))
+            if slot is None:
+                return
+            tr.xch_put(slot, m)
+            with tr.mixed_region():
+                state["acc"][j] = tr.fma(m, state["umc"][k], state["acc"][j])
+                if k != j:
+                    state["acc"][k] = tr.fma(m, state["umc"][j], state["acc"][k])
+        alg.direct_minv(tr, spec, X, I, between=between, on_final=on_final)
         for j in range(n):
-            tr.xch_put(slots.qdd[j], qdd[j])
+            tr.xch_put(slots.qdd[j], state["acc"][j])
         tr.barrier()
     else:
         c = alg.rnea(tr, spec, X, I, qd, None, g)[0]
@@ -191,15 +206,61 @@ def _coop_prologue(tr, spec, slots, role, X, I, qd, u, g):
     return [tr.xch_get(slots.qdd[j]) for j in range(n)]
 
 
-def core_forward_dynamics_gradient_coop(spec, role, cols, slots):
+def exchange_dependence(tr):
+    """dep[k]: node k depends (transitively) on a value read from the exchange region (i.e. on another wave's result)."""
+    dep = [False] * len(tr.nodes)
+    for k in range(1, len(tr.nodes)):
+        op, a = tr.nodes[k][0], tr.nodes[k][1]
+        dep[k] = str(a).startswith("in.xch_get(") if op == "in" else any(dep[d] for d in tr._deps(k))
+    return dep
+
+
+def coop_phase_costs(tr):
+    """(instructions that can be issued before the first barrier, instructions that need another wave's result): arithmetic
+    of the live part of a tile-cooperative core, split by exchange_dependence; exchange reads count with the second part."""
+    dep = exchange_dependence(tr)
+    live = tr.live_nodes()
+    arith = ("fma", "mul", "add", "pkfma", "pkmul", "pkadd")
+    p1 = sum(1 for k in range(1, len(tr.nodes)) if live[k] and not dep[k] and tr.nodes[k][0] in arith)
+    p2 = sum(1 for k in range(1, len(tr.nodes)) if live[k] and dep[k] and (tr.nodes[k][0] in arith or tr.nodes[k][0] == "in"))
+    return p1, p2
+
+
+def hoist_before_first_barrier(tr):
+    """Demand-order cores only.  Everything a core needs that does NOT depend on the exchange region is forced in front of its
+    first barrier: the frontier of that independent part (values whose users all wait for another wave) is anchored there.
+    While the producer wave runs the Minv recursion the other waves then do ~3/4 of their gradient work (dv, the whole d/dqd
+    half, every velocity product) instead of waiting; what is left behind the barriers is only what depends on qdd."""
+    dep = exchange_dependence(tr)
+    live = tr.live_nodes()
+    users = [[] for _ in tr.nodes]
+    for k in range(1, len(tr.nodes)):
+        if live[k]:
+            for d in tr._deps(k):
+                users[d].append(k)
+    first = next(i for i, (dst, _) in enumerate(tr.outputs) if dst == "barrier")
+    later_direct = set(abs(r) for (dst, r) in tr.outputs[first:] if not isinstance(r, float))
+    frontier = [k for k in range(1, len(tr.nodes)) if live[k] and not dep[k] and tr.nodes[k][0] != "in"
+                and (any(dep[u] for u in users[k]) or k in later_direct)]
+    pos = tr.out_pos[first]
+    tr.outputs[first:first] = [("anchor", k) for k in frontier]
+    tr.out_pos[first:first] = [pos] * len(frontier)
+    return len(frontier)
+
+
+def core_forward_dynamics_gradient_coop(spec, role, cols, slots, hoist=False):
     """Fused forward-dynamics-gradient core of ONE wave of a tile-cooperative block (small robots).  The block's waves share
-    the prefix instead of repeating it (column-split kernels): one wave computes Minv while the others compute the bias
-    torques, results cross through LDS, then every wave finishes qdd = Minv (u - c) and its own group of gradient columns.
-    Same arithmetic, in the same order, as core_forward_dynamics_gradient (bit-identical results in fp32)."""
+    the prefix instead of repeating it (column-split kernels): one wave computes Minv and qdd while the others compute the bias
+    torques; results cross through LDS; then every wave differentiates its own columns.  cols may be empty (a producer without
+    columns).  hoist=True (experimental, measured slower: 12.9 vs 12.1 us for iiwa-7 at K = 16384) additionally forces every
+    part of a consumer's columns that does not depend on qdd in front of the first barrier (hoist_before_first_barrier).
+    Same arithmetic per value as core_forward_dynamics_gradient."""
     assert role in COOP_ROLES
     n = spec.n
     tr, ins, g, X, I = _setup(spec, ["q", "qd", "u"])
     qdd = _coop_prologue(tr, spec, slots, role, X, I, ins["qd"], ins["u"], g)
+    if not cols:
+        return tr
     Mx = {}
     for (r, k), slot in slots.minv.items():
         Mx[(r, k)] = tr.xch_get(slot)
@@ -208,6 +269,8 @@ def core_forward_dynamics_gradient_coop(spec, role, cols, slots):
     dc = alg.rnea_grad(tr, spec, X, I, ins["qd"], v, a, f, g)
     out = alg.fd_grad_finish(tr, spec, Minv, dc, cols)
     _out_grad(tr, spec, out, cols)
+    if hoist and role != "producer":
+        hoist_before_first_barrier(tr)
     return tr
 
 
