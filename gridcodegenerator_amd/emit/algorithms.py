@@ -157,7 +157,7 @@ def rnea(tr, spec, X, I, qd, qdd, gravity):
 def direct_minv(tr, spec, X, I, between=None, on_final=None):
     """Upper-triangular Minv[j][k] (k >= j) as traced scalars; entries k < j are None.
 
-    between(): called between the backward and the forward pass.  on_final(j, k, value): called as soon as Minv[j][k] has its
+    between(carried): called between the backward and the forward pass with the backward-pass values the forward pass uses.  on_final(j, k, value): called as soon as Minv[j][k] has its
     final value (row j is final when the forward pass has visited joint j) -- a consumer that uses the entry right there (the
     tile-cooperative producer publishes it and folds it into qdd) lets it die instead of keeping all n(n+1)/2 alive."""
     with tr.mixed_region():
@@ -211,7 +211,10 @@ def _direct_minv(tr, spec, X, I, between=None, on_final=None):
                 IA[p][r][c] = val
                 IA[p][c][r] = val
     if between is not None:
-        between()
+        # everything the forward pass still needs from the backward pass (for emitters that must pin it before a barrier)
+        carried = [Dinv[j] for j in range(n)] + [U[j][r] for j in range(n) for r in range(6)]
+        carried += [Minv[j][k] for j in range(n) for k in range(j, n) if Minv[j][k] is not None]
+        between(carried)
     Fn = {}      # forward-pass F (the reference overwrites F in place, _test.py:198-200)
     for j in range(n):
         p, s = spec.parent[j], spec.S_ind[j]

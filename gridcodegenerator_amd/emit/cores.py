@@ -161,7 +161,7 @@ class CoopSlots:
 COOP_ROLES = ("producer", "consumer_c", "consumer")
 
 
-def _coop_prologue(tr, spec, slots, role, X, I, qd, u, g):
+def _coop_prologue(tr, spec, slots, role, X, I, qd, u, g, demand_order=True):
     """Phases 1 and 2 of a tile-cooperative core; returns qdd (read from the exchange region by every wave).
 
     producer:  backward pass of the Minv recursion | barrier | c from the exchange region; forward pass: every entry of Minv is
@@ -175,7 +175,10 @@ def _coop_prologue(tr, spec, slots, role, X, I, qd, u, g):
         # two passes of the recursion (the consumers have long finished RNEA by then)
         state = {}
 
-        def between():
+        def between(carried):
+            if demand_order:             # demand-order emission: the backward pass must be issued BEFORE the wave waits
+                for val in carried:      # (creation-order emission places the barrier where it is traced)
+                    tr.anchor(val)
             tr.barrier()
             with tr.mixed_region():
                 state["umc"] = [u[j] - tr.xch_get(slots.c[j]) for j in range(n)]
@@ -757,7 +760,7 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
         mark = tr.cse_mark()
         u = [tr.inp("in.u(%d)" % j) for j in range(n)]
         X = alg.build_X(tr, spec, q, trig)
-        qdd = list(_coop_prologue(tr, spec, slots, role, X, I, qd, u, g))
+        qdd = list(_coop_prologue(tr, spec, slots, role, X, I, qd, u, g, demand_order=False))
         tr.fence()
         tr.cse_release(mark, keep=[t.ref for pair in trig if pair is not None for t in pair])
     elif kind == "fd" and not use_qdd_minv:

@@ -101,7 +101,7 @@ int grid_get_split(grid_handle *h, int alg, int num_timesteps);
  * One block of 4 wavefronts per tile of 64 configurations: one wave runs the Minv recursion while the others run RNEA, the
  * results cross through LDS, then every wave differentiates its own group of columns.  Unlike the column-split kernels the
  * shared prefix is computed ONCE per tile.  grid_coop_available: 1 if the generator emitted it for `alg` (GRID_ALG_FD_DU).
- * grid_set_coop: 0 = automatic (default: large robots for 192..767 tiles, measured policy), 1 = never, 2 = always.
+ * grid_set_coop: 0 = automatic (default: large robots from 192 tiles on, measured policy), 1 = never, 2 = always.
  * grid_get_coop: 1 if a call with `num_timesteps` would dispatch it (it takes precedence over the column split). */
 int grid_coop_available(int alg);
 int grid_set_coop(grid_handle *h, int alg, int mode);

@@ -27,7 +27,7 @@ def test_every_kernel_is_within_the_build_guard(robot, precision):
 def test_small_robot_kernels_do_not_touch_scratch():
     for precision in ("fp32", "mixed"):
         for k in _resources("iiwa7", precision):
-            assert k["sgpr_spills"] <= 10, k
+            assert k["sgpr_spills"] <= 16, k
             if "split2" not in k["name"]:      # (the 2-way split is capped at 256 registers for two waves per SIMD: 1 / 51 spilled values)
                 assert k["scratch"] == 0, k
             else:
