@@ -411,6 +411,12 @@ class AlgorithmEmitMixin:
         if not cand:
             return base, []
         cost = cores.range_cost_function(self.spec, builder, exact=(n <= 8))
+        if getattr(builder, "recompute", False):
+            # column-serial kernels flush one column half at a time, and a lone wavefront pays each flush's LDS round trips and store
+            # issue in full: ~340 instruction slots per half (measured: the 16-column group of the Atlas-30 dID split was the slowest
+            # by 20 us although the groups were balanced on arithmetic).  Balance on arithmetic + flushes.
+            arith_cost = cost
+            cost = lambda b, e: arith_cost(b, e) + self.FLUSH_SLOTS_PER_COLUMN * (e - b)
         use_sets = (self.split_sets and n <= 8 and self.out_mode == "staged" and not getattr(builder, "recompute", False))
         full = builder(None) if use_sets else None
         picked = []
@@ -425,7 +431,7 @@ class AlgorithmEmitMixin:
             else:
                 parts, est = cores.balanced_column_split(self.spec, S, cost)
                 if getattr(builder, "recompute", False) and n > 12 and len(parts) == S:
-                    parts, est = cores.refine_contiguous_split(parts, builder)      # exact costs (the model is poor here)
+                    parts, est = cores.refine_contiguous_split(parts, builder, per_column=self.FLUSH_SLOTS_PER_COLUMN)      # exact costs
             if len(parts) != S or any(not c for c in parts):
                 continue
             if self.grad_splits != "auto" or n <= 8 or getattr(builder, "recompute", False) or est < 0.97 * last:
@@ -1040,6 +1046,7 @@ class AlgorithmEmitMixin:
     # tile-cooperative forward-dynamics gradient: the waves of a block share one tile of 64 configurations
     # ------------------------------------------------------------------------------------------
     COOP_WAVES = 4
+    FLUSH_SLOTS_PER_COLUMN = 600      # instruction-issue slots one gradient column (two flushes of n values) costs a lone wavefront
 
     def _coop_groups_fused(self, builder, slots):
         """Column groups for the fused (small-robot) cooperative cores, chosen on a timeline model of the block:
@@ -1097,8 +1104,8 @@ class AlgorithmEmitMixin:
             barriers = [pos for (dst, _), pos in zip(tr.outputs, tr.out_pos) if dst == "barrier"]
             start = barriers[-1]
             arith = ("fma", "mul", "add", "pkfma", "pkmul", "pkadd")
-            return sum(1 for k in range(start, len(tr.nodes)) if live[k] and (tr.nodes[k][0] in arith or (
-                tr.nodes[k][0] == "in" and str(tr.nodes[k][1]).startswith("in.xch_get("))))
+            return self.FLUSH_SLOTS_PER_COLUMN * len(cols) + sum(1 for k in range(start, len(tr.nodes)) if live[k] and (
+                tr.nodes[k][0] in arith or (tr.nodes[k][0] == "in" and str(tr.nodes[k][1]).startswith("in.xch_get("))))
         single = {role: [ops(role, [c]) for c in range(n)] for role in ("producer", "consumer")}
         base = {role: min(single[role]) for role in single}
         marg = {role: [x - base[role] for x in single[role]] for role in single}

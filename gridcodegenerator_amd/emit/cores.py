@@ -388,7 +388,7 @@ def balanced_column_split(spec, S, cost):
     bounds = bounds[::-1]
     return [list(range(bounds[i], bounds[i + 1])) for i in range(S)], best[S][n]
 
-def refine_contiguous_split(parts, builder, max_steps=8):
+def refine_contiguous_split(parts, builder, max_steps=8, per_column=0):
     """Hill-climb a contiguous column split on EXACT group costs (each evaluation traces a group): move one boundary column
     out of the most expensive group into its neighbour while that lowers the maximum.  Used where the prefix + marginal
     model of range_cost_function is poor (large robots, dFD: the Minv rows a group needs depend on its columns; Atlas-30
@@ -399,7 +399,7 @@ def refine_contiguous_split(parts, builder, max_steps=8):
     def cost(p):
         key = (p[0], p[-1])
         if key not in memo:
-            memo[key] = _arith_ops(builder(list(p)))
+            memo[key] = _arith_ops(builder(list(p))) + per_column * len(p)      # (+ what flushing the columns costs a lone wave)
         return memo[key]
 
     for _ in range(max_steps):

@@ -297,6 +297,13 @@ class Tracer:
         fresh_hi = (not isinstance(rH.ref, float)) and abs(rH.ref) == len(self.nodes) - 1 and len(self.nodes) == n_after_lo + 1
         if not (self.use_packed and fresh_lo and fresh_hi):
             return P(self, rL, rH)
+        # gfx950's VOP3P encoding has no literal operand: a model constant inside a packed instruction has to come from an SGPR
+        # (s_mov_b32 with a literal costs a lone wave 8 cycles; tools/ubench/packed_cost.hip: 6.4 cycles per result against 5.5
+        # for two scalar v_fmaak_f32).  Operations with a constant operand therefore stay two scalar instructions on the halves;
+        # only (pair x per-lane value) and (pair + pair) are packed (3.0 cycles per result).
+        operands = [aL, aH, bL, bH] + ([cL, cH] if cL is not None else [])
+        if any(isinstance(o.ref, float) and o.ref != 0.0 for o in operands):
+            return P(self, rL, rH)
         kL, kH = self.nodes[abs(rL.ref)][0], self.nodes[abs(rH.ref)][0]
         if kL not in ("fma", "mul", "add") or kH not in ("fma", "mul", "add"):
             return P(self, rL, rH)

@@ -417,8 +417,8 @@ class RuntimeEmitMixin:
             "        // read-modify-written at the loop latch (1126 VGPR + 183 SGPR spills, 1.7 KB scratch per lane; DESIGN.md section 9).",
             "        const int ol = grid_opaque(lane);",
             "        GRID_GLOBAL T *urow = grid_opaque_uniform(d_dst + (size_t)k0*ROW);      // row of the tile's first configuration, wave-uniform",
-            "        const int g = ol / P; const int ii = ol % P;",
             "        grid_wave_sync();",
+            "        const int g = ol / P; const int ii = ol % P;",
             "        if (W != GRID_WAVE_SIZE){           // partial wavefront (block size not a multiple of 64): generic path",
             "            for (int f = ol; f < nvalid*LEN; f += W){",
             "                const int cfg = f / LEN; const int i = f - cfg*LEN;",

@@ -282,8 +282,9 @@ def _build_library_locked(robot_name, precision, force, verbose, extra_flags, ge
             h = hashlib.sha256(header_hash.encode())
         with open(cmd[-3], "rb") as fh:
             h.update(fh.read())
-        with open(os.path.join(INCLUDE_DIR, "grid_capi.h"), "rb") as fh:
-            h.update(fh.read())
+        if inst is None:        # only the C-ABI unit includes grid_capi.h
+            with open(os.path.join(INCLUDE_DIR, "grid_capi.h"), "rb") as fh:
+                h.update(fh.read())
         h.update(" ".join(a for a in cmd[1:-3] if not a.startswith("-I") and not a.startswith("-DGRID_HEADER=") and not a.startswith("-DGRID_INST=")).encode())
         return h.hexdigest()
 
