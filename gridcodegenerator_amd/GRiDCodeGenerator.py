@@ -86,6 +86,13 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin, Verific
             if large and grad_schedule == "fused":
                 raise ValueError("grad_schedule='fused' with %d joints miscomputed on the GPU (spilled 2.5-4.7 KB per lane); "
                                  "use 'recompute' or pass allow_unverified=True" % self.spec.n)
+            if trig != "fast":
+                raise ValueError("trig=%r inlines the math library's sincos, whose large-argument path is a lane-divergent branch: kernels "
+                                 "with such branches are unverified (hipcc placed spill code inside the masked region, DESIGN.md "
+                                 "section 9); use trig='fast' (branch-free, |q| <= 1e6) or pass allow_unverified=True" % trig)
+            if exp["out_mode"] == "direct":
+                raise ValueError("out_mode='direct' wraps the core in a per-lane `if`: lane-divergent control flow is unverified "
+                                 "(DESIGN.md section 9); pass allow_unverified=True to build it anyway")
             if large and int(waves_per_simd) > 1:
                 raise ValueError("waves_per_simd > 1 with %d joints reproduces the register-capped kernels that faulted on the GPU; "
                                  "pass allow_unverified=True to build them anyway" % self.spec.n)

@@ -244,7 +244,8 @@ class AlgorithmEmitMixin:
         sig += "const robotModel<T> *d_robotModel, " + ("const T gravity, " if has_gravity else "") + "const int NUM_TIMESTEPS)"
         self.gen_add_func_doc(doc + " -- single-configuration latency twin",
                               ["NUM_TIMESTEPS is overloaded as the number of timing repetitions (as in the reference)",
-                               "every lane of the launch evaluates configuration 0; lane 0 of block 0 writes d_%s[0..%d)" % (out_name, n_out)],
+                               "every lane of the launch evaluates configuration 0; the lanes of block 0's first wave (all holding the same",
+                               "values) write d_%s[0..%d) -- a wave-uniform condition, so the kernel has no lane-divergent branch" % (out_name, n_out)],
                               [], None)
         self.gen_add_code_line("template <typename T, typename C = typename grid_compute<T>::type>")
         self.gen_add_code_line("__global__ __launch_bounds__(GRID_MAX_THREADS)")
@@ -262,7 +263,12 @@ class AlgorithmEmitMixin:
         if table:
             self.gen_add_code_line("T s_tab[%d];" % table)
         self.gen_add_code_line("const grid_in_ptrs<T> in = {%s%s};" % (accessor, ", s_tab" if table else ""))
-        self.gen_add_code_line("grid_out_first<T> out = {d_%s, blockIdx.x == 0 && threadIdx.x == 0};" % out_name)
+        self.gen_add_code_line("#if defined(__HIP_DEVICE_COMPILE__)")
+        self.gen_add_code_line("const bool first_wave = (blockIdx.x == 0) && (__builtin_amdgcn_readfirstlane((int)threadIdx.x) == 0);   // wave-uniform: scalar branch, EXEC untouched")
+        self.gen_add_code_line("#else")
+        self.gen_add_code_line("const bool first_wave = true;")
+        self.gen_add_code_line("#endif")
+        self.gen_add_code_line("grid_out_first<T> out = {d_%s, first_wave};" % out_name)
         self.gen_add_code_line("for (int rep = 0; rep < NUM_TIMESTEPS; rep++){", True)
         for (an, ac) in arrays:
             for i0 in range(0, ac, 8):
@@ -413,8 +419,8 @@ class AlgorithmEmitMixin:
         cost = cores.range_cost_function(self.spec, builder, exact=(n <= 8))
         if getattr(builder, "recompute", False):
             # column-serial kernels flush one column half at a time, and a lone wavefront pays each flush's LDS round trips and store
-            # issue in full: ~340 instruction slots per half (measured: the 16-column group of the Atlas-30 dID split was the slowest
-            # by 20 us although the groups were balanced on arithmetic).  Balance on arithmetic + flushes.
+            # issue in full: ~200 instruction slots per half with the pair path (measured: the 16-column group of the Atlas-30 dID
+            # split was the slowest by 20 us although the groups were balanced on arithmetic).  Balance on arithmetic + flushes.
             arith_cost = cost
             cost = lambda b, e: arith_cost(b, e) + self.FLUSH_SLOTS_PER_COLUMN * (e - b)
         use_sets = (self.split_sets and n <= 8 and self.out_mode == "staged" and not getattr(builder, "recompute", False))
@@ -1046,7 +1052,7 @@ class AlgorithmEmitMixin:
     # tile-cooperative forward-dynamics gradient: the waves of a block share one tile of 64 configurations
     # ------------------------------------------------------------------------------------------
     COOP_WAVES = 4
-    FLUSH_SLOTS_PER_COLUMN = 600      # instruction-issue slots one gradient column (two flushes of n values) costs a lone wavefront
+    FLUSH_SLOTS_PER_COLUMN = 400      # instruction-issue slots one gradient column (two flushes of n values) costs a lone wavefront
 
     def _coop_groups_fused(self, builder, slots):
         """Column groups for the fused (small-robot) cooperative cores, chosen on a timeline model of the block:

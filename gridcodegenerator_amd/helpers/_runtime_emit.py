@@ -182,10 +182,12 @@ class RuntimeEmitMixin:
         else:
             self.gen_add_code_lines([
                 "// ~25 instructions instead of ~100 for the library sincosf: 3-term Cody-Waite reduction by pi/2 (exact with fma)",
-                "// + Cephes minimax polynomials on [-pi/4, pi/4]; max abs error 9.3e-8 for |x| <= 1e5 (library: 7e-8); larger",
-                "// arguments (never a joint angle) take the library path",
+                "// + Cephes minimax polynomials on [-pi/4, pi/4]; max abs error 9.3e-8 for |x| <= 1e5 and 1.0e-7 up to 1e6 (library:",
+                "// 7e-8).  BRANCH-FREE on purpose: no lane-divergent control flow anywhere in a generated kernel (DESIGN.md section 9:",
+                "// hipcc placed register spills inside the reduced-exec region of exactly such a branch).  The price is the range:",
+                "// beyond 1e6 rad (never a joint angle) the reduction loses accuracy (1e-4 at 1e7) and beyond 2.6e7 it is meaningless;",
+                "// non-finite input gives NaN like the library.  trig=\"libm\" / \"f64\" keep the library's full-range reduction.",
                 "__host__ __device__ __forceinline__ void grid_sincos(float x, float *s, float *c){",
-                "    if (__builtin_expect(!(__builtin_fabsf(x) <= 1.0e5f), 0)){sincosf(x, s, c); return;}",
                 "    const float k = __builtin_rintf(x*0.636619772367581343f);",
                 "    float r = __builtin_fmaf(-k, 1.5707963705062866f, x); r = __builtin_fmaf(-k, -4.371138828673793e-08f, r); r = __builtin_fmaf(-k, -1.7763568394002505e-15f, r);",
                 "    const float z = r*r;",
@@ -281,7 +283,7 @@ class RuntimeEmitMixin:
             "template <typename T>",
             "struct grid_out_first {",
             "    T *p_; bool on_;",
-            "    __host__ __device__ __forceinline__ void put(int i, T v){if (on_){p_[i] = v;}}",
+            "    __host__ __device__ __forceinline__ void put(int i, T v){if (on_){p_[i] = v;}}    // on_ is WAVE-UNIFORM (every lane of the first wave holds the same row)",
             "};",
             "",
             "// ---- wave-level staging: W lanes <-> W consecutive configurations (W = 64 for whole waves), no block barrier ----",
@@ -377,7 +379,8 @@ class RuntimeEmitMixin:
             "            #pragma unroll",
             "            for (int t = 0; t < N; t++){",
             "                const int f = t*Wo + lane; const int cfg = f / N; const int i = f - cfg*N;",
-            "                tmp[t] = (cfg < nvalid) ? src[(unsigned)(cfg*stride + i)] : static_cast<T>(0);",
+            "                const T v = src[(unsigned)(min(cfg, nvalid - 1)*stride + i)];     // clamped read + select: no lane-divergent branch",
+            "                tmp[t] = (cfg < nvalid) ? v : static_cast<T>(0);",
             "            }",
             "        }",
             "        #pragma unroll",
@@ -415,41 +418,82 @@ class RuntimeEmitMixin:
             "        // range) into its own 64-bit pointer induction variable of the tile loop: the Atlas-30 gradient kernels carried",
             "        // ~100 such pointer pairs across the whole straight-line core -- 200 registers, most of them living in scratch and",
             "        // read-modify-written at the loop latch (1126 VGPR + 183 SGPR spills, 1.7 KB scratch per lane; DESIGN.md section 9).",
+            "        // NO LANE-DIVERGENT CONTROL FLOW.  Every condition below is wave-uniform (scalar branches); lanes that have nothing of",
+            "        // their own to write (run length not a power of two, ragged last tile) repeat the last valid element -- same address,",
+            "        // same value, merged by the coalescer -- so EXEC never changes inside a kernel.  hipcc placed register spill code inside",
+            "        // the reduced-EXEC region of a divergent branch (the spills then did not happen for the masked lanes: DESIGN.md",
+            "        // section 9); with no such region there is nowhere to misplace it, and tests/test_kernel_budget.py checks the ISA.",
             "        const int ol = grid_opaque(lane);",
             "        GRID_GLOBAL T *urow = grid_opaque_uniform(d_dst + (size_t)k0*ROW);      // row of the tile's first configuration, wave-uniform",
             "        grid_wave_sync();",
-            "        const int g = ol / P; const int ii = ol % P;",
-            "        if (W != GRID_WAVE_SIZE){           // partial wavefront (block size not a multiple of 64): generic path",
-            "            for (int f = ol; f < nvalid*LEN; f += W){",
+            "        if (W != GRID_WAVE_SIZE){           // partial wavefront (block size not a multiple of 64): generic path, uniform trip count",
+            "            const int total = nvalid*LEN;",
+            "            for (int f0 = 0; f0 < total; f0 += W){",
+            "                const int f = min(f0 + ol, total - 1);",
             "                const int cfg = f / LEN; const int i = f - cfg*LEN;",
             "                urow[(size_t)cfg*ROW + base + i] = s_wave[f];",
             "            }",
+            "            grid_wave_sync();",
+            "            return;",
             "        }",
-            "        else if (ii < LEN){",
-            "            const T *src = s_wave + (g*LEN + ii);",
-            "            GRID_GLOBAL T *ubase = urow + base;                  // wave-uniform",
-            "            const unsigned vob = (unsigned)(g*ROW + ii)*(unsigned)sizeof(T);   // per lane, BYTES, 32 bit: SGPR base + VGPR offset addressing",
-            "            if (nvalid == GRID_WAVE_SIZE){   // full tile: no per-iteration predicate",
-            "                constexpr int NIT = GRID_WAVE_SIZE/G;",
-            "                if constexpr (NIT % 8 == 0){",
-            "                    // groups of 8 written out by hand (8 LDS reads in flight, then 8 stores) so that the shape does not",
-            "                    // depend on the optimisation level (-O1 keeps a `#pragma unroll` loop rolled: one LDS round trip per element)",
-            "                    for (int t = 0; t < NIT; t += 8){",
-            "                        const T *s = src + t*G*LEN; GRID_GLOBAL T *d = ubase + (size_t)t*(G*ROW);     // uniform advance (scalar adds)",
-            "                        const T a0 = s[0*G*LEN], a1 = s[1*G*LEN], a2 = s[2*G*LEN], a3 = s[3*G*LEN];",
-            "                        const T a4 = s[4*G*LEN], a5 = s[5*G*LEN], a6 = s[6*G*LEN], a7 = s[7*G*LEN];",
-            "                        grid_at(d + 0*G*ROW, vob) = a0; grid_at(d + 1*G*ROW, vob) = a1; grid_at(d + 2*G*ROW, vob) = a2; grid_at(d + 3*G*ROW, vob) = a3;",
-            "                        grid_at(d + 4*G*ROW, vob) = a4; grid_at(d + 5*G*ROW, vob) = a5; grid_at(d + 6*G*ROW, vob) = a6; grid_at(d + 7*G*ROW, vob) = a7;",
+            "        if constexpr (LEN % 2 == 0 && ROW % 2 == 0 && sizeof(T) == 4){",
+            "            // PAIRS: even run length, even row length, even offset, 8-byte aligned buffer, full tile -> two values per lane and",
+            "            // instruction (ds_read_b64 + global_store_dwordx2): half the LDS reads and half the stores.  A lone wavefront pays",
+            "            // every LDS round trip and every store issue of a flush in full -- for a 30-joint robot the flushes were a third",
+            "            // of the slowest column group's time (profiles/r02/sq_atlas_dID_split4_16384_summary.txt).",
+            "            if (nvalid == GRID_WAVE_SIZE && (base & 1) == 0 && (reinterpret_cast<unsigned long long>(d_dst) & 7ull) == 0){",
+            "                typedef T T2 __attribute__((ext_vector_type(2)));",
+            "                constexpr int L2 = LEN/2;",
+            "                constexpr int P2 = (L2 <= 1) ? 1 : (L2 <= 2) ? 2 : (L2 <= 4) ? 4 : (L2 <= 8) ? 8 : (L2 <= 16) ? 16 : (L2 <= 32) ? 32 : 64;",
+            "                constexpr int G2 = GRID_WAVE_SIZE / P2;",
+            "                constexpr int NIT2 = GRID_WAVE_SIZE / G2;",
+            "                const int g2 = ol / P2; const int i2 = min(ol % P2, L2 - 1);",
+            "                const T2 *src2 = reinterpret_cast<const T2 *>(s_wave) + (g2*L2 + i2);",
+            "                GRID_GLOBAL T2 *ub2 = (GRID_GLOBAL T2 *)(urow + base);",
+            "                const unsigned vob2 = (unsigned)(g2*(ROW/2) + i2)*(unsigned)sizeof(T2);",
+            "                if constexpr (NIT2 % 8 == 0){",
+            "                    for (int t = 0; t < NIT2; t += 8){",
+            "                        const T2 *s = src2 + t*G2*L2; GRID_GLOBAL T2 *d = ub2 + (size_t)t*(G2*(ROW/2));",
+            "                        const T2 a0 = s[0*G2*L2], a1 = s[1*G2*L2], a2 = s[2*G2*L2], a3 = s[3*G2*L2];",
+            "                        const T2 a4 = s[4*G2*L2], a5 = s[5*G2*L2], a6 = s[6*G2*L2], a7 = s[7*G2*L2];",
+            "                        grid_at(d + 0*G2*(ROW/2), vob2) = a0; grid_at(d + 1*G2*(ROW/2), vob2) = a1; grid_at(d + 2*G2*(ROW/2), vob2) = a2; grid_at(d + 3*G2*(ROW/2), vob2) = a3;",
+            "                        grid_at(d + 4*G2*(ROW/2), vob2) = a4; grid_at(d + 5*G2*(ROW/2), vob2) = a5; grid_at(d + 6*G2*(ROW/2), vob2) = a6; grid_at(d + 7*G2*(ROW/2), vob2) = a7;",
             "                    }",
             "                }",
             "                else {",
             "                    #pragma unroll",
-            "                    for (int t = 0; t < NIT; t++){grid_at(ubase + (size_t)t*(G*ROW), vob) = src[t*G*LEN];}",
+            "                    for (int t = 0; t < NIT2; t++){grid_at(ub2 + (size_t)t*(G2*(ROW/2)), vob2) = src2[t*G2*L2];}",
+            "                }",
+            "                grid_wave_sync();",
+            "                return;",
+            "            }",
+            "        }",
+            "        const int g = ol / P; const int ii = min(ol % P, LEN - 1);",
+            "        GRID_GLOBAL T *ubase = urow + base;                  // wave-uniform",
+            "        if (nvalid == GRID_WAVE_SIZE){   // full tile",
+            "            const T *src = s_wave + (g*LEN + ii);",
+            "            const unsigned vob = (unsigned)(g*ROW + ii)*(unsigned)sizeof(T);   // per lane, BYTES, 32 bit: SGPR base + VGPR offset addressing",
+            "            constexpr int NIT = GRID_WAVE_SIZE/G;",
+            "            if constexpr (NIT % 8 == 0){",
+            "                // groups of 8 written out by hand (8 LDS reads in flight, then 8 stores) so that the shape does not",
+            "                // depend on the optimisation level (-O1 keeps a `#pragma unroll` loop rolled: one LDS round trip per element)",
+            "                for (int t = 0; t < NIT; t += 8){",
+            "                    const T *s = src + t*G*LEN; GRID_GLOBAL T *d = ubase + (size_t)t*(G*ROW);     // uniform advance (scalar adds)",
+            "                    const T a0 = s[0*G*LEN], a1 = s[1*G*LEN], a2 = s[2*G*LEN], a3 = s[3*G*LEN];",
+            "                    const T a4 = s[4*G*LEN], a5 = s[5*G*LEN], a6 = s[6*G*LEN], a7 = s[7*G*LEN];",
+            "                    grid_at(d + 0*G*ROW, vob) = a0; grid_at(d + 1*G*ROW, vob) = a1; grid_at(d + 2*G*ROW, vob) = a2; grid_at(d + 3*G*ROW, vob) = a3;",
+            "                    grid_at(d + 4*G*ROW, vob) = a4; grid_at(d + 5*G*ROW, vob) = a5; grid_at(d + 6*G*ROW, vob) = a6; grid_at(d + 7*G*ROW, vob) = a7;",
             "                }",
             "            }",
             "            else {",
-            "                #pragma unroll 2",
-            "                for (int t = 0; t < GRID_WAVE_SIZE/G; t++){if (t*G + g < nvalid){grid_at(ubase + (size_t)t*(G*ROW), vob) = src[t*G*LEN];}}",
+            "                #pragma unroll",
+            "                for (int t = 0; t < NIT; t++){grid_at(ubase + (size_t)t*(G*ROW), vob) = src[t*G*LEN];}",
+            "            }",
+            "        }",
+            "        else {                           // ragged last tile: configurations past the end repeat the last valid one",
+            "            for (int t = 0; t*G < nvalid; t++){",
+            "                const int cfg = min(t*G + g, nvalid - 1);",
+            "                grid_at(ubase, (unsigned)(cfg*ROW + ii)*(unsigned)sizeof(T)) = s_wave[cfg*LEN + ii];",
             "            }",
             "        }",
             "        grid_wave_sync();",

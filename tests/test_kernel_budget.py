@@ -27,7 +27,7 @@ def test_every_kernel_is_within_the_build_guard(robot, precision):
 def test_small_robot_kernels_do_not_touch_scratch():
     for precision in ("fp32", "mixed"):
         for k in _resources("iiwa7", precision):
-            assert k["sgpr_spills"] <= 16, k
+            assert k["sgpr_spills"] <= 32, k     # (mixed: double constants live in SGPR pairs; SGPR spills go to VGPR lanes, not scratch)
             if "split2" not in k["name"]:      # (the 2-way split is capped at 256 registers for two waves per SIMD: 1 / 51 spilled values)
                 assert k["scratch"] == 0, k
             else:
@@ -44,6 +44,37 @@ def test_atlas_column_groups_are_spill_free_after_the_addressing_fix():
     assert dfd["scratch"] <= 700 and dfd["vgpr_spills"] <= 260, dfd
     coop = res["forward_dynamics_gradient_kernel_coop"]
     assert coop["scratch"] <= host.MAX_SCRATCH_BYTES_PER_LANE, coop
+
+
+@pytest.mark.parametrize("robot,precision", [("iiwa7", "fp32"), ("mixed5", "fp32"), ("atlas30", "fp32"), ("iiwa7", "mixed"), ("mixed5", "mixed")])
+def test_no_kernel_writes_exec(robot, precision):
+    """No lane-divergent control flow in any shipped kernel (gridcodegenerator_amd/isa_audit.py): hipcc placed
+    spill code -- among it the copy of the lane id -- at the head of the join block of a divergent branch, before the `s_or_b64 exec`
+    that restores the mask, and the masked lanes' spills never happened (wild stores, memory faults at small batches).  The ISA of
+    every kernel of every library is disassembled here and must not contain a single instruction that writes EXEC."""
+    from gridcodegenerator_amd import isa_audit
+    lib = host.library_paths(robot, precision)["lib"]
+    if not os.path.exists(lib):
+        pytest.skip("library not built (run __graft_entry__.build())")
+    res = isa_audit.audit(lib)
+    assert len(res) >= 17
+    assert all(n > 500 for (n, _) in res.values()), "disassembly incomplete"
+    assert {isa_audit.short_name(k): e for k, (n, e) in res.items() if e} == {}
+
+
+def test_the_audit_sees_exec_writes(tmp_path):
+    """The audit's pattern against a kernel that does have a lane-divergent branch (compiled here, a few seconds)."""
+    from gridcodegenerator_amd import isa_audit
+    src = tmp_path / "k.hip"
+    src.write_text("#include <hip/hip_runtime.h>\n__global__ void divergent(float *p){if (threadIdx.x & 1){p[threadIdx.x] = __sinf(p[threadIdx.x]);} p[threadIdx.x + 64] = 1.f;}\n"
+                   "__global__ void uniform(float *p, int n){for (int i = 0; i < n; i++){p[threadIdx.x + 64*i] = 2.f;}}\n")
+    obj = tmp_path / "k.o"
+    import subprocess
+    subprocess.check_call([host._hipcc(), "--offload-arch=gfx950", "-O2", "-c", str(src), "-o", str(obj)])
+    res = {k: v for k, v in isa_audit.audit(str(obj)).items()}
+    div = [v for k, v in res.items() if "divergent" in k][0]
+    uni = [v for k, v in res.items() if "uniform" in k][0]
+    assert div[1] >= 1 and uni[1] == 0, res
 
 
 def test_resource_parser():
