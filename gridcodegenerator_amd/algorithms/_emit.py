@@ -1137,24 +1137,27 @@ class AlgorithmEmitMixin:
             if key not in exact:
                 exact[key] = ops(role_of(i), list(range(*pr)))
             return exact[key]
-        for _ in range(8 if n > 8 else 0):
-            costs = [cost_exact(i, parts[i]) for i in range(W)]
-            worst = max(range(W), key=lambda i: costs[i])
-            improved = None
-            for nb in (worst - 1, worst + 1):
-                if nb < 0 or nb >= W or parts[worst][1] - parts[worst][0] < 2:
-                    continue
-                trial = list(parts)
-                if nb < worst:      # give the first column of `worst` to the group before it
-                    trial[nb] = (parts[nb][0], parts[nb][1] + 1); trial[worst] = (parts[worst][0] + 1, parts[worst][1])
-                else:               # give the last column to the group after it
-                    trial[worst] = (parts[worst][0], parts[worst][1] - 1); trial[nb] = (parts[nb][0] - 1, parts[nb][1])
-                new_max = max(cost_exact(i, trial[i]) for i in range(W))
-                if new_max < costs[worst] and (improved is None or new_max < improved[0]):
-                    improved = (new_max, trial)
-            if improved is None:
+        # coordinate descent on the W-1 cut points (moves of one or two columns; a move may first make the maximum worse for a
+        # neighbour that a later move relieves, so ties on the maximum are broken by the sum of squares)
+        def score(pp):
+            cs = [cost_exact(i, pp[i]) for i in range(W)]
+            return (max(cs), sum(c * c for c in cs))
+        for _ in range(12 if n > 8 else 0):
+            cur = score(parts)
+            best_move = None
+            for cut in range(1, W):
+                for step in (-2, -1, 1, 2):
+                    pos = parts[cut][0] + step
+                    if pos <= parts[cut - 1][0] or pos >= parts[cut][1]:
+                        continue
+                    trial = list(parts)
+                    trial[cut - 1] = (parts[cut - 1][0], pos); trial[cut] = (pos, parts[cut][1])
+                    sc = score(trial)
+                    if sc < cur and (best_move is None or sc < best_move[0]):
+                        best_move = (sc, trial)
+            if best_move is None:
                 break
-            parts = improved[1]
+            parts = best_move[1]
         groups = [("producer", list(range(*parts[-1])))]
         for role, pr in zip(roles[1:], parts[:-1]):
             groups.append((role, list(range(*pr))))

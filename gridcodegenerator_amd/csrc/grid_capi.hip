@@ -30,6 +30,7 @@ struct grid_handle {
     int split[5];   // per algorithm: 0 = auto, 1 = never split, S = force the S-way column-split kernel
     int pipeline[5];   // per algorithm: 0 = auto (single kernel), 1 = single kernel, 2 = two-pass (workspace) variant
     int coop[5];       // per algorithm: 0 = auto, 1 = never, 2 = always the tile-cooperative kernel (where generated)
+    int unsplit_regs[5];   // registers of the unsplit kernel (hipFuncGetAttributes at init): <= 256 means two waves share a SIMD
     T *d_workspace; size_t workspace_bytes; hipStream_t workspace_stream; bool workspace_busy;
 };
 
@@ -87,6 +88,7 @@ int grid_init(int device, grid_handle **out) {
     h->device = device; h->hd_data = nullptr; h->max_timesteps = 0;
     for (int a = 0; a < 5; a++) { h->split[a] = 0; h->pipeline[a] = 0; h->coop[a] = 0; }
     h->d_workspace = nullptr; h->workspace_bytes = 0; h->workspace_stream = nullptr; h->workspace_busy = false;
+    for (int a = 0; a < 5; a++) { int attr[4] = {0, 0, 0, 0}; h->unsplit_regs[a] = (grid_kernel_attributes(a, 0, attr) == 0) ? attr[0] : 512; }
     h->d_robotModel = G::init_robotModel<T>();
     h->streams = G::init_grid<T>();
     if (int rc = grid_check("grid_init")) { delete h; return rc; }
@@ -204,8 +206,9 @@ int grid_forward_dynamics_gradient(grid_handle *h, const float *h_q_qd_u, const 
 // RNEA) for more wavefronts.  Measured on MI355X (iiwa-7 FD gradient, tools/exp_splits.py): it pays while the batch leaves
 // SIMDs idle, so pick the largest S with tiles*S <= 4 x 256 (one wave on every SIMD; the finer splits are compiled without
 // a register cap and a second wave on a SIMD would serialise behind the first).  K=16384: 17.7 us (S=1), 13.6 (S=2),
-// 12.4 (S=3), 11.5 (S=4), 18.3 (S=5).  For batches that already fill the chip the 2-way split still wins by 5-12 % when it
-// exists (its 256-register kernels run two waves per SIMD; the unsplit kernel needs > 256 registers): K=1M: 319 -> 285 us.
+// 12.4 (S=3), 11.5 (S=4), 18.3 (S=5).  For batches that already fill the chip what counts is two waves per SIMD: the unsplit
+// kernel when it fits 256 registers (iiwa-7 dFD since the kernels are branch-free: K=262144 53 us against 77 us for the 2-way
+// split, 1M: 202 against 321 us), otherwise the register-capped 2-way split (round 1: unsplit needed 280 registers, 319 -> 285 us).
 static const int GRID_CUS = 256;   // MI355X
 static int available_splits(int alg, const int **list) {
     if (alg == GRID_ALG_FD_DU) { *list = G::FD_DU_SPLITS; return G::FD_DU_NUM_SPLITS; }
@@ -231,7 +234,7 @@ static int effective_split(const grid_handle *h, int alg, int K) {
         return best;
     }
     for (int i = 0; i < n; i++) if ((long long)tiles * list[i] <= 4LL * GRID_CUS && list[i] > best) best = list[i];
-    if (best == 1 && G::NUM_JOINTS <= 12) { for (int i = 0; i < n; i++) if (list[i] == 2) best = 2; }
+    if (best == 1 && G::NUM_JOINTS <= 12 && h->unsplit_regs[alg] > 256) { for (int i = 0; i < n; i++) if (list[i] == 2) best = 2; }
     return best;
 }
 

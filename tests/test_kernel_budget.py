@@ -16,7 +16,10 @@ def _resources(robot, precision):
     return res
 
 
-@pytest.mark.parametrize("robot,precision", [("iiwa7", "fp32"), ("mixed5", "fp32"), ("atlas30", "fp32"), ("iiwa7", "mixed"), ("mixed5", "mixed")])
+ALL_LIBRARIES = [("iiwa7", "fp32"), ("mixed5", "fp32"), ("atlas30", "fp32"), ("iiwa7", "mixed"), ("mixed5", "mixed"), ("atlas30", "mixed")]
+
+
+@pytest.mark.parametrize("robot,precision", ALL_LIBRARIES)
 def test_every_kernel_is_within_the_build_guard(robot, precision):
     for k in _resources(robot, precision):
         assert k["scratch"] <= host.MAX_SCRATCH_BYTES_PER_LANE, k
@@ -46,7 +49,7 @@ def test_atlas_column_groups_are_spill_free_after_the_addressing_fix():
     assert coop["scratch"] <= host.MAX_SCRATCH_BYTES_PER_LANE, coop
 
 
-@pytest.mark.parametrize("robot,precision", [("iiwa7", "fp32"), ("mixed5", "fp32"), ("atlas30", "fp32"), ("iiwa7", "mixed"), ("mixed5", "mixed")])
+@pytest.mark.parametrize("robot,precision", ALL_LIBRARIES)
 def test_no_kernel_writes_exec(robot, precision):
     """No lane-divergent control flow in any shipped kernel (gridcodegenerator_amd/isa_audit.py): hipcc placed
     spill code -- among it the copy of the lane id -- at the head of the join block of a divergent branch, before the `s_or_b64 exec`

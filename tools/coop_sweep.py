@@ -5,7 +5,8 @@ import numpy as np, torch
 from gridcodegenerator_amd import host
 robot, precision = sys.argv[1], sys.argv[2]
 Ks = [int(x) for x in sys.argv[3].split(',')]
-host.build_library(robot, precision)
+import os
+if not os.environ.get('GRID_USE_PREBUILT'): host.build_library(robot, precision)
 h = host.GridHandle(robot, precision=precision); n = h.n
 alg = host.ALG_FD_DU
 for a in ("unsplit", "coop"):

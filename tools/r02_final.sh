@@ -18,5 +18,10 @@ timeout -k 10 300 python tools/coop_sweep.py atlas30 fp32 64,4096,8192,16384,327
 timeout -k 10 200 python tools/coop_sweep.py iiwa7 fp32 64,1024,4096,16384,65536,262144,1048576 > $out/sweep_iiwa7_fp32.txt 2>&1 || { echo "sweep iiwa7 FAILED rc=$?"; exit 1; }; echo "sweep iiwa7 ok"; tail -9 $out/sweep_iiwa7_fp32.txt
 timeout -k 10 200 python tools/latency.py iiwa7 fp32 > $out/latency_iiwa7.txt 2>&1 || { echo "latency FAILED rc=$?"; exit 1; }; echo "latency ok"
 timeout -k 10 200 python tools/latency.py atlas30 fp32 > $out/latency_atlas30.txt 2>&1 || { echo "latency atlas FAILED rc=$?"; exit 1; }; echo "latency atlas ok"
+timeout -k 10 400 python tests/gpu_checks/precision_report.py fp32 > $out/precision_report_fp32.txt 2>&1 || { echo "precision fp32 FAILED rc=$?"; exit 1; }; echo "precision fp32 ok"
+timeout -k 10 400 python tests/gpu_checks/precision_report.py mixed > $out/precision_report_mixed.txt 2>&1 || { echo "precision mixed FAILED rc=$?"; exit 1; }; echo "precision mixed ok"
+timeout -k 10 300 python bench.py --robot atlas30 --batch 16384 --precision mixed --no-secondary --steps 50 --warmup 5 > $out/bench_atlas30_16384_mixed.json 2>> $out/bench.err || { echo "bench atlas mixed FAILED rc=$?"; exit 1; }; echo "bench atlas mixed ok"
+timeout -k 10 300 python tools/ksweep_all.py atlas30 fp32 64,1024,4096,16384,65536 > $out/ksweep_atlas30_fp32.txt 2>&1 || { echo "ksweep FAILED rc=$?"; exit 1; }; echo "ksweep ok"
+timeout -k 10 300 python tools/coop_sweep.py atlas30 mixed 64,4096,16384,65536 > $out/sweep_atlas30_mixed.txt 2>&1 || { echo "sweep atlas mixed FAILED rc=$?"; exit 1; }; echo "sweep atlas mixed ok"
 timeout -k 10 120 ./tools/ubench/phase_stamps > $out/phase_stamps.txt 2>&1 || { echo "stamps FAILED rc=$?"; exit 1; }; echo "stamps ok"
 find $out -name "*.csv" | head -12
