@@ -78,14 +78,17 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin, Verific
         self.robot = robotObj
         self.spec = RobotSpec(robotObj)
         large = self.spec.n > 12
-        # combinations that faulted, hung or miscomputed on the GPU are refused at generation time
+        # Round 1's failing variants (fp64, fused n > 12, register caps on large robots: DESIGN.md section 9) were spill code inside
+        # reduced-EXEC regions (section 9.1); the kernels are branch-free now and the variants are regression-tested on the GPU
+        # (tests/test_round1_regressions.py).  What is still refused is what has not been re-verified, and what reintroduces
+        # lane-divergent control flow.
         if not allow_unverified:
-            if precision == "fp64":
-                raise ValueError("precision='fp64' kernels are unverified on the GPU (wrong results / hangs in round 1); use "
-                                 "'mixed' (double where cond(M) amplifies) or pass allow_unverified=True")
+            if precision == "fp64" and large:
+                raise ValueError("precision='fp64' is verified on the GPU for robots with n <= 12 only (all-double kernels of a %d-joint "
+                                 "robot have not been built); use 'mixed' or pass allow_unverified=True" % self.spec.n)
             if large and grad_schedule == "fused":
-                raise ValueError("grad_schedule='fused' with %d joints miscomputed on the GPU (spilled 2.5-4.7 KB per lane); "
-                                 "use 'recompute' or pass allow_unverified=True" % self.spec.n)
+                raise ValueError("grad_schedule='fused' with %d joints has not been re-verified on the GPU since round 1 (it miscomputed "
+                                 "then, DESIGN.md section 9); use 'recompute' or pass allow_unverified=True" % self.spec.n)
             if trig != "fast":
                 raise ValueError("trig=%r inlines the math library's sincos, whose large-argument path is a lane-divergent branch: kernels "
                                  "with such branches are unverified (hipcc placed spill code inside the masked region, DESIGN.md "
@@ -93,9 +96,6 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin, Verific
             if exp["out_mode"] == "direct":
                 raise ValueError("out_mode='direct' wraps the core in a per-lane `if`: lane-divergent control flow is unverified "
                                  "(DESIGN.md section 9); pass allow_unverified=True to build it anyway")
-            if large and int(waves_per_simd) > 1:
-                raise ValueError("waves_per_simd > 1 with %d joints reproduces the register-capped kernels that faulted on the GPU; "
-                                 "pass allow_unverified=True to build them anyway" % self.spec.n)
         self.allow_unverified = bool(allow_unverified)
         self._chunks = []
         self.indent_level = 0

@@ -411,7 +411,9 @@ class AlgorithmEmitMixin:
             cand = sorted(set([2, 3, 4, n])) if n <= 8 else ([2, 4] if (n <= 12 or getattr(builder, "recompute", False)) else [])
             limit = 4
         else:
-            cand = [int(S) for S in self.grad_splits]
+            # entries are split factors S (the columns are grouped automatically) or explicit partitions [[cols], [cols], ...]
+            explicit = {len(e): [list(c) for c in e] for e in self.grad_splits if not isinstance(e, int)}
+            cand = sorted(set([int(S) for S in self.grad_splits if isinstance(S, int)] + list(explicit)))
             limit = len(cand)
         base = cores._arith_ops(builder(None))
         if not cand:
@@ -430,7 +432,11 @@ class AlgorithmEmitMixin:
         for S in cand:
             if S > n:
                 continue
-            if use_sets and S >= 3:
+            if self.grad_splits != "auto" and S in explicit:
+                parts = explicit[S]
+                assert sorted(c for part in parts for c in part) == list(range(n)), "an explicit partition must cover every column once"
+                est = max(cores._arith_ops(builder(c)) for c in parts)
+            elif use_sets and S >= 3:
                 # arbitrary column sets (exhaustive, exact: cores.optimal_column_sets) for the splits that serve small batches;
                 # the 2-way split serves full-chip batches, where contiguous columns give 3-4x longer store runs
                 parts, est = cores.optimal_column_sets(self.spec, S, full)

@@ -334,16 +334,16 @@ def _build_library_locked(robot_name, precision, force, verbose, extra_flags, ge
         fh.write("### link (rc=%d)\n%s\n%s\n" % (proc.returncode, " ".join(link), proc.stdout))
     if proc.returncode != 0:
         raise GridLibraryError("link failed for %s (see %s):\n%s" % (p["tag"], p["log"], proc.stdout[-4000:]))
-    if not gen_kwargs.get("allow_unverified"):
-        # no lane-divergent control flow in a shipped kernel (isa_audit.py: hipcc misplaced spill code inside reduced-EXEC regions)
-        from . import isa_audit
-        bad = isa_audit.offenders(p["lib"] + ".tmp")
-        with open(p["log"], "a") as fh:
-            fh.write("### isa audit: %s\n" % (bad or "no kernel writes EXEC"))
-        if bad:
-            os.remove(p["lib"] + ".tmp")
-            raise GridLibraryError("%s: kernels with lane-divergent control flow (instructions writing EXEC): %s -- such builds are "
-                                   "unverified (DESIGN.md section 9); pass allow_unverified=True to build them anyway" % (p["tag"], bad))
+    # no lane-divergent control flow in a shipped kernel (isa_audit.py: hipcc misplaced spill code inside reduced-EXEC regions).
+    # The audit always runs and is logged; allow_unverified turns a finding into a logged warning (explicitly divergent options).
+    from . import isa_audit
+    bad = isa_audit.offenders(p["lib"] + ".tmp")
+    with open(p["log"], "a") as fh:
+        fh.write("### isa audit: %s\n" % (bad or "no kernel writes EXEC"))
+    if bad and not gen_kwargs.get("allow_unverified"):
+        os.remove(p["lib"] + ".tmp")
+        raise GridLibraryError("%s: kernels with lane-divergent control flow (instructions writing EXEC): %s -- such builds are "
+                               "unverified (DESIGN.md section 9); pass allow_unverified=True to build them anyway" % (p["tag"], bad))
     os.replace(p["lib"] + ".tmp", p["lib"])
     with open(p["stamp"], "w") as fh:
         fh.write(fp)

@@ -46,8 +46,12 @@ def code_objects(path, arch="gfx950"):
 
 
 def short_name(mangled):
-    m = re.match(r"_ZN\d+(grid_[A-Za-z0-9_]*?)(\d+)([a-z_0-9]+)I", mangled)      # _ZN<len><namespace><len><kernel>I...
-    return mangled if not m else m.group(3)[:int(m.group(2))]
+    m = re.match(r"_ZN(\d+)", mangled)                     # _ZN<len><namespace><len><kernel>I...
+    if not m:
+        return mangled
+    rest = mangled[m.end() + int(m.group(1)):]
+    m2 = re.match(r"(\d+)", rest)
+    return mangled if not m2 else rest[m2.end():m2.end() + int(m2.group(1))]
 
 
 def audit(path, arch="gfx950"):
