@@ -150,12 +150,15 @@ class Workload:
         q, qd, u = make_inputs(n, K, seed)
         self.d_in = torch.from_numpy(np.ascontiguousarray(np.concatenate([q, qd, u], axis=1))).cuda()
         self.d_out = torch.empty((K, 2 * n * n), dtype=torch.float32, device="cuda")
+        # torch's current stream (0 = the default stream: GridHandle passes it on as hipStreamLegacy; a NULL pointer would mean the
+        # handle's own non-blocking stream to the C ABI, which is not ordered with torch's work)
         self.stream = torch.cuda.current_stream().cuda_stream
-        # streams > 1: consecutive steps (independent batches) go round-robin over extra streams, each with its own output buffer,
-        # so that the dispatch / end-of-kernel gap of one launch overlaps with the next one's execution
+        # streams > 1: consecutive steps (independent batches) go round-robin over streams created here, each with its own output
+        # buffer, so that the dispatch / end-of-kernel gap of one launch overlaps with the next one's execution.  None of them is
+        # the default stream: work on the default stream waits for every blocking stream and would serialise the round-robin.
         self.n_streams = max(1, int(streams))
-        self.extra_streams = [torch.cuda.Stream() for _ in range(self.n_streams - 1)]
-        self.stream_ptrs = [self.stream] + [st.cuda_stream for st in self.extra_streams]
+        self.extra_streams = [torch.cuda.Stream() for _ in range(self.n_streams if self.n_streams > 1 else 0)]
+        self.stream_ptrs = [st.cuda_stream for st in self.extra_streams] or [self.stream]
         self.outs = [self.d_out] + [torch.empty_like(self.d_out) for _ in range(self.n_streams - 1)]
         self.step_no = 0
         self.blocks, self.threads = blocks, threads
@@ -276,6 +279,9 @@ def main():
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    # a stream of its own as torch's current stream: torch's work and the launches (Workload.stream) are ordered on it, and the
+    # launches avoid the default stream's implicit synchronisation with every other blocking stream
+    torch.cuda.set_stream(torch.cuda.Stream())
     dist = sharding.init_distributed("gloo" if rehearsal else "nccl")
     reduce_device = "cpu" if rehearsal else "cuda"
 

@@ -523,6 +523,9 @@ def _fp(a):
     return a.ctypes.data_as(_c_float_p)
 
 
+HIP_STREAM_LEGACY = 1      # hipStreamLegacy ((hipStream_t)1): the default (NULL) stream as an explicit handle
+
+
 class GridHandle:
     """One robot model on one GPU: ``init_robotModel`` + ``init_grid`` (+ ``init_gridData``)."""
 
@@ -532,8 +535,23 @@ class GridHandle:
         self._h = _vp()
         self.L.check(self.L.lib.grid_init(int(device), ctypes.byref(self._h)), "grid_init")
         self.max_timesteps = 0
+        # stream used by the device-pointer methods when none is passed: None = the handle's own first stream (the C ABI's NULL).
+        # NOTE: like the reference's init_grid this stream is created NON-BLOCKING, i.e. it is NOT ordered with work on the default
+        # stream (PyTorch's default stream included).  Set `default_stream = 0` (or pass stream=...) to launch on the default stream.
+        self.default_stream = None
         if max_timesteps:
             self.alloc(max_timesteps)
+
+    def _stream(self, stream):
+        """The `stream` argument of the device-pointer methods -> what the C ABI gets.  None: `default_stream` (None there: the
+        handle's own non-blocking stream).  0: the default (NULL) stream -- this is what `torch.cuda.current_stream().cuda_stream`
+        reports for PyTorch's default stream -- passed on as hipStreamLegacy, because a NULL pointer means "the handle's stream"
+        to the C ABI.  Anything else: that stream handle."""
+        if stream is None:
+            stream = self.default_stream
+        if stream is None:
+            return None
+        return HIP_STREAM_LEGACY if int(stream) == 0 else int(stream)
 
     # lifecycle ------------------------------------------------------------------------------------
     def alloc(self, max_timesteps):
@@ -613,30 +631,30 @@ class GridHandle:
 
     # device-pointer calls (reference mode 2); pointers are ints (e.g. torch.Tensor.data_ptr()) --------------
     def inverse_dynamics_device(self, d_c, d_q_qd, stride, K, d_qdd=None, gravity=9.81, blocks=0, threads=0, stream=None):
-        self.L.check(self.L.lib.grid_inverse_dynamics_device(self._h, d_c, d_q_qd, stride, d_qdd, K, gravity, blocks, threads, stream),
+        self.L.check(self.L.lib.grid_inverse_dynamics_device(self._h, d_c, d_q_qd, stride, d_qdd, K, gravity, blocks, threads, self._stream(stream)),
                      "grid_inverse_dynamics_device")
 
     def direct_minv_device(self, d_Minv, d_q, stride, K, blocks=0, threads=0, stream=None):
-        self.L.check(self.L.lib.grid_direct_minv_device(self._h, d_Minv, d_q, stride, K, blocks, threads, stream), "grid_direct_minv_device")
+        self.L.check(self.L.lib.grid_direct_minv_device(self._h, d_Minv, d_q, stride, K, blocks, threads, self._stream(stream)), "grid_direct_minv_device")
 
     def forward_dynamics_device(self, d_qdd, d_q_qd_u, stride, K, gravity=9.81, blocks=0, threads=0, stream=None):
-        self.L.check(self.L.lib.grid_forward_dynamics_device(self._h, d_qdd, d_q_qd_u, stride, K, gravity, blocks, threads, stream),
+        self.L.check(self.L.lib.grid_forward_dynamics_device(self._h, d_qdd, d_q_qd_u, stride, K, gravity, blocks, threads, self._stream(stream)),
                      "grid_forward_dynamics_device")
 
     def inverse_dynamics_gradient_device(self, d_dc_du, d_q_qd, stride, K, d_qdd=None, gravity=9.81, blocks=0, threads=0, stream=None):
-        self.L.check(self.L.lib.grid_inverse_dynamics_gradient_device(self._h, d_dc_du, d_q_qd, stride, d_qdd, K, gravity, blocks, threads, stream),
+        self.L.check(self.L.lib.grid_inverse_dynamics_gradient_device(self._h, d_dc_du, d_q_qd, stride, d_qdd, K, gravity, blocks, threads, self._stream(stream)),
                      "grid_inverse_dynamics_gradient_device")
 
     def forward_dynamics_gradient_device(self, d_df_du, d_q_qd_u, stride, K, d_qdd=None, d_Minv=None, gravity=9.81,
                                          blocks=0, threads=0, stream=None):
         self.L.check(self.L.lib.grid_forward_dynamics_gradient_device(self._h, d_df_du, d_q_qd_u, stride, d_qdd, d_Minv, K, gravity,
-                                                                      blocks, threads, stream), "grid_forward_dynamics_gradient_device")
+                                                                      blocks, threads, self._stream(stream)), "grid_forward_dynamics_gradient_device")
 
     def forward_dynamics_gradient_rollout_device(self, d_traj, d_x0, d_u_traj, K, num_steps, dt, gravity=9.81, blocks=0, threads=0, stream=None):
         """Semi-implicit Euler rollout with linearisation (include/grid_capi.h): d_traj is time-major
         [num_steps][K][rollout_row_count] = [x+ | A | B] per step."""
         self.L.check(self.L.lib.grid_forward_dynamics_gradient_rollout_device(self._h, d_traj, d_x0, d_u_traj, K, num_steps, dt, gravity,
-                                                                               blocks, threads, stream), "grid_forward_dynamics_gradient_rollout_device")
+                                                                               blocks, threads, self._stream(stream)), "grid_forward_dynamics_gradient_rollout_device")
 
     def rollout_row_count(self):
         return int(self.L.lib.grid_rollout_row_count())
@@ -663,11 +681,11 @@ class GridHandle:
         return int(self.L.lib.grid_get_split(self._h, alg, int(K)))
 
     def synchronize(self, stream=None):
-        self.L.check(self.L.lib.grid_synchronize(self._h, stream), "grid_synchronize")
+        self.L.check(self.L.lib.grid_synchronize(self._h, self._stream(stream)), "grid_synchronize")
 
     def time_device(self, alg, d_out, d_in, stride, K, d_qdd=None, d_Minv=None, gravity=9.81, blocks=0, threads=0, stream=None, reps=20):
         ms = ctypes.c_float(0.0)
-        self.L.check(self.L.lib.grid_time_device(self._h, alg, d_out, d_in, stride, d_qdd, d_Minv, K, gravity, blocks, threads, stream,
+        self.L.check(self.L.lib.grid_time_device(self._h, alg, d_out, d_in, stride, d_qdd, d_Minv, K, gravity, blocks, threads, self._stream(stream),
                                                  reps, ctypes.byref(ms)), "grid_time_device")
         return float(ms.value)
 

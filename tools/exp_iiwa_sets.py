@@ -15,6 +15,11 @@ for name, parts in VARIANTS.items():
     if name not in robots.REGISTERED_ROBOTS:
         robots.register_robot(name, lambda: robots.get_robot("iiwa7"))
     host.DEFAULT_GEN_KWARGS[name] = dict(grad_splits=[parts])
+# the generator's own exhaustive search over column sets (experimental split_sets), per algorithm
+VARIANTS["iiwa7_setsAuto"] = "optimal_column_sets per algorithm"
+if "iiwa7_setsAuto" not in robots.REGISTERED_ROBOTS:
+    robots.register_robot("iiwa7_setsAuto", lambda: robots.get_robot("iiwa7"))
+host.DEFAULT_GEN_KWARGS["iiwa7_setsAuto"] = dict(grad_splits=[4], experimental={"split_sets": True})
 
 if __name__ == "__main__":
     if sys.argv[1] == "build":
