@@ -398,7 +398,7 @@ class AlgorithmEmitMixin:
             return lambda cols: cores.core_inverse_dynamics_gradient(self.spec, False, cols)
         return lambda cols: cores.core_forward_dynamics_gradient(self.spec, False, cols)
 
-    def _choose_splits(self, builder):
+    def _choose_splits(self, builder, displace_first=False):
         """Column-split variants worth emitting: [(S, parts, worst part's op count)], each step improving >= 3 %."""
         n = self.spec.n
         if self.grad_splits == "auto":
@@ -442,6 +442,23 @@ class AlgorithmEmitMixin:
                 parts, est = cores.optimal_column_sets(self.spec, S, full)
             else:
                 parts, est = cores.balanced_column_split(self.spec, S, cost)
+                if displace_first and n <= 8 and 3 <= S < n and self.out_mode == "staged" and not getattr(builder, "recompute", False):
+                    # A base joint about the gravity axis makes column 0 almost free (its d/dq half is structurally zero), and a
+                    # contiguous split then wastes a whole wave on it (iiwa-7 dID, 4-way: [[0],[1],[2],[3..6]]).  Alternative: split
+                    # columns 1.. contiguously and give column 0 to the group it burdens least (one non-contiguous group, flushed
+                    # per column).  Measured, iiwa-7 K = 16384: dID 9.5 -> 8.6 us (profiles/r02/exp_iiwa7_column_sets_4way.txt).  NOT
+                    # for dFD: same time there, but the kernel needs 262 instead of 256 registers (one wave per SIMD: two streams no
+                    # longer overlap, 2.2 -> 1.6 G evals/s) and writes 12 % more (per-column runs): dID only.
+                    rest, _ = cores.balanced_column_split(self.spec, S, cost, first=1)
+                    if len(rest) == S and all(rest):
+                        exact = lambda cols: cores._arith_ops(builder(list(cols)))
+                        trials = [[([0] + g if i == k else list(g)) for i, g in enumerate(rest)] for k in range(S)]
+                        alt = min(trials, key=lambda t: max(exact(g) for g in t))
+                        alt_est = max(exact(g) for g in alt)
+                        if alt_est < 0.97 * max(exact(g) for g in parts):
+                            # heaviest group first: block b takes group b % S, and the blocks dispatched first should be the ones
+                            # that run longest (measured: the same groups in ascending order cost the 4-way dFD split 2 %)
+                            parts, est = sorted(alt, key=exact, reverse=True), alt_est
                 if getattr(builder, "recompute", False) and n > 12 and len(parts) == S:
                     parts, est = cores.refine_contiguous_split(parts, builder, per_column=self.FLUSH_SLOTS_PER_COLUMN)      # exact costs
             if len(parts) != S or any(not c for c in parts):
@@ -457,7 +474,7 @@ class AlgorithmEmitMixin:
 
     def _emit_split_family(self, alg, kernel_base, core_base, doc, out_name, primary, has_gravity, accessor, builder, launch_args):
         """Cores + kernels + a launcher for the column-split variants of a gradient kernel."""
-        base, chosen = self._choose_splits(builder)
+        base, chosen = self._choose_splits(builder, displace_first=(alg == "ID_DU"))
         self.split_stats[alg] = dict(base_ops=base, splits={S: dict(parts=[list(c) for c in parts], worst_ops=worst)
                                                              for (S, parts, worst) in chosen})
         for (S, parts, worst) in chosen:

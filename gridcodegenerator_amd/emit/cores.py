@@ -362,18 +362,18 @@ def range_cost_function(spec, builder, exact):
     return lambda b, e: prefix + pre[e] - pre[b]
 
 
-def balanced_column_split(spec, S, cost):
-    """Split columns 0..n-1 into S contiguous ranges minimising the largest part's operation count.
+def balanced_column_split(spec, S, cost, first=0):
+    """Split columns first..n-1 into S contiguous ranges minimising the largest part's operation count.
     Returns (parts, ops of the largest part according to `cost`)."""
     n = spec.n
-    S = max(1, min(S, n))
+    S = max(1, min(S, n - first))
     INF = float("inf")
     best = [[INF] * (n + 1) for _ in range(S + 1)]
     cut = [[0] * (n + 1) for _ in range(S + 1)]
-    best[0][0] = 0
+    best[0][first] = 0
     for k in range(1, S + 1):
-        for e in range(k, n + 1):
-            for b in range(k - 1, e):
+        for e in range(first + k, n + 1):
+            for b in range(first + k - 1, e):
                 if best[k - 1][b] == INF:
                     continue
                 c = max(best[k - 1][b], cost(b, e))
