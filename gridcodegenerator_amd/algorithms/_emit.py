@@ -1123,7 +1123,15 @@ class AlgorithmEmitMixin:
         (the producer must recompute RNEA there, the consumers only its qdd-dependent part).  The producer takes the LAST
         group (late columns are the cheapest).  Returns [(role, cols)], producer first."""
         n, W = self.spec.n, self.COOP_WAVES
-        roles = ["producer", "consumer_c"] + ["consumer"] * (W - 2)
+        two = slots.ksplit is not None
+        # role of the wave that takes group i (groups in column order): the first group goes to the wave that publishes c, the
+        # last to the producer -- with two producers the last two (late columns are the cheapest)
+        def role_name(i):
+            if i == W - 1:
+                return "producer"
+            if two and i == W - 2:
+                return "producer2"
+            return "consumer_c" if i == 0 else "consumer"
         def ops(role, cols):
             # what decides the block's time is the work AFTER the second barrier: every wave leaves it at the same moment (when the
             # producer has published qdd), so the block finishes with the wave that has the most phase-2 instructions
@@ -1140,19 +1148,19 @@ class AlgorithmEmitMixin:
         marg = {role: [x - base[role] for x in single[role]] for role in single}
 
         def cost(role, b, e):
-            r = "producer" if role == "producer" else "consumer"
+            r = "producer" if role.startswith("producer") else "consumer"
             return base[r] + sum(marg[r][b:e])
         best = None
         import itertools
         for cuts in itertools.combinations(range(1, n), W - 1):
             bounds = (0,) + cuts + (n,)
             parts = [(bounds[i], bounds[i + 1]) for i in range(W)]
-            worst = max([cost("producer", *parts[-1])] + [cost("consumer", *p) for p in parts[:-1]])
+            worst = max(cost(role_name(i), *parts[i]) for i in range(W))
             if best is None or worst < best[0]:
                 best = (worst, parts)
         parts = list(best[1])
         # the additive model is rough for large robots (what a column costs depends on its neighbours): hill-climb on EXACT costs
-        role_of = lambda i: "producer" if i == W - 1 else "consumer"
+        role_of = lambda i: ("consumer" if role_name(i) == "consumer_c" else role_name(i))
         exact = {}
 
         def cost_exact(i, pr):
@@ -1181,10 +1189,29 @@ class AlgorithmEmitMixin:
             if best_move is None:
                 break
             parts = best_move[1]
-        groups = [("producer", list(range(*parts[-1])))]
-        for role, pr in zip(roles[1:], parts[:-1]):
-            groups.append((role, list(range(*pr))))
-        return groups
+        order = [W - 1] + ([W - 2] if two else []) + [i for i in range(W - 1) if not (two and i == W - 2)]      # producer(s) first
+        return [(role_name(i), list(range(*parts[i]))) for i in order]
+
+    def _coop_prefix_split(self, builder, slots):
+        """Column k0 at which two producer waves divide the forward pass of the Minv recursion (columns k < k0 | k >= k0): the one
+        that minimises the larger of the two waves' arithmetic up to the second barrier (each wave's trace keeps only the part of
+        the backward pass its own columns need)."""
+        n = self.spec.n
+        arith = ("fma", "mul", "add", "pkfma", "pkmul", "pkadd")
+
+        def between_barriers(role, k0):
+            slots.ksplit = k0
+            tr = builder(role, [], slots)
+            live = tr.live_nodes()
+            b = [pos for (dst, _), pos in zip(tr.outputs, tr.out_pos) if dst == "barrier"]
+            return sum(1 for k in range(1, b[1]) if live[k] and tr.nodes[k][0] in arith)
+        best = None
+        for k0 in range(n // 4, n - n // 8):
+            worst = max(between_barriers("producer", k0), between_barriers("producer2", k0))
+            if best is None or worst < best[0]:
+                best = (worst, k0)
+        slots.ksplit = None
+        return best[1]
 
     def gen_forward_dynamics_gradient_coop(self, use_thread_group=False):
         """`forward_dynamics_gradient_kernel_coop`: one block of COOP_WAVES wavefronts per tile of 64 configurations.  The
@@ -1202,6 +1229,11 @@ class AlgorithmEmitMixin:
         rec = (self.grad_schedule == "recompute")
         if rec:
             builder = lambda role, cols, sl: cores.core_gradient_recompute(self.spec, "fd", cols=cols, coop=(role, sl))
+            if n > 12 and self.precision != "mixed":
+                # Two producer waves: the serial prefix (backward pass 4.4 k + forward pass and qdd 3.4 k arithmetic instructions for
+                # Atlas-30, during which the consumers idle) shrinks by the half of the forward pass the second producer takes.
+                # Not in the mixed arithmetic: the two shares of qdd = Minv (u - c) would be rounded to float before they are added.
+                slots.ksplit = self._coop_prefix_split(builder, slots)
         else:
             builder = lambda role, cols, sl: cores.core_forward_dynamics_gradient_coop(self.spec, role, cols, sl, hoist=self.coop_hoist)
         groups = self._coop_groups_fused(builder, slots) if (self.coop_hoist and not rec) else self._coop_groups(builder, slots)

@@ -137,8 +137,8 @@ def core_forward_dynamics_gradient(spec, use_qdd_minv, cols=None):
 
 class CoopSlots:
     """Exchange-region slots of the tile-cooperative forward-dynamics-gradient kernels: the structurally non-zero upper
-    triangle of Minv, then the bias torques c / the accelerations qdd (same slots, used one after the other).  Value `slot` of
-    lane l lives at slot*64 + l of the block's LDS region."""
+    triangle of Minv, then the bias torques c and the accelerations qdd (two shares when two producer waves split the forward
+    pass of the Minv recursion).  Value `slot` of lane l lives at slot*64 + l of the block's LDS region."""
 
     def __init__(self, spec):
         n = spec.n
@@ -148,9 +148,15 @@ class CoopSlots:
             for k in range(r, n):
                 if nz[r][k]:
                     self.minv[(r, k)] = len(self.minv)
-        self.c = [len(self.minv) + j for j in range(n)]
-        self.qdd = list(self.c)         # c is read only by the producer, before it publishes qdd: the slots are shared
-        self.count = len(self.minv) + n
+        base = len(self.minv)
+        self.c = [base + j for j in range(n)]
+        self.qdd = [base + n + j for j in range(n)]            # qdd = Minv (u - c), or the first producer's share of it
+        self.qdd2 = [base + 2 * n + j for j in range(n)]       # the second producer's share (ksplit is not None)
+        self.count = base + 3 * n
+        # Two producer waves (large robots): both run the backward pass of the Minv recursion, then "producer" finishes the
+        # columns k < ksplit of the forward pass and "producer2" the columns k >= ksplit (the forward pass is independent per
+        # column); each folds its entries into its own share of qdd.  None: one producer does everything.
+        self.ksplit = None
 
     def entry(self, tr, r, k):
         """Minv_sym[r][k] as a fresh exchange read (None: structural zero)."""
@@ -158,7 +164,7 @@ class CoopSlots:
         return tr.xch_get(slot) if slot is not None else None
 
 
-COOP_ROLES = ("producer", "consumer_c", "consumer")
+COOP_ROLES = ("producer", "producer2", "consumer_c", "consumer")
 
 
 def _coop_prologue(tr, spec, slots, role, X, I, qd, u, g, demand_order=True):
@@ -167,13 +173,19 @@ def _coop_prologue(tr, spec, slots, role, X, I, qd, u, g, demand_order=True):
     producer:  backward pass of the Minv recursion | barrier | c from the exchange region; forward pass: every entry of Minv is
                published as it becomes final and folded into qdd = Minv (u - c) right there (in double when the build is
                mixed-precision, so the cond(M)-amplified product sees the unrounded Minv) -> qdd to the exchange region | barrier
+    producer2: (slots.ksplit set) the same backward pass, the columns k >= ksplit of the forward pass and its share of qdd
     consumers: RNEA at qdd = 0 while the producer is busy; one of them publishes c | barrier | barrier"""
     n = spec.n
-    if role == "producer":
+    two = slots.ksplit is not None
+    assert two or role != "producer2"
+    if role in ("producer", "producer2"):
         # Minv entries are published -- and folded into qdd = Minv_sym (u - c) -- the moment they are final, so they never all
         # live at once (465 values for Atlas-30); c is needed from the forward pass on, so the first barrier sits between the
-        # two passes of the recursion (the consumers have long finished RNEA by then)
+        # two passes of the recursion (the consumers have long finished RNEA by then).  With two producers each finishes,
+        # publishes and folds only its own columns; the other columns' forward-pass arithmetic is dead code in its trace.
         state = {}
+        mine = (lambda k: True) if not two else ((lambda k: k < slots.ksplit) if role == "producer" else (lambda k: k >= slots.ksplit))
+        out_slots = slots.qdd if role == "producer" else slots.qdd2
 
         def between(carried):
             if demand_order:             # demand-order emission: the backward pass must be issued BEFORE the wave waits
@@ -186,7 +198,7 @@ def _coop_prologue(tr, spec, slots, role, X, I, qd, u, g, demand_order=True):
 
         def on_final(j, k, m):
             slot = slots.minv.get((j, k))
-            if slot is None:
+            if slot is None or not mine(k):
                 return
             tr.xch_put(slot, m)
             with tr.mixed_region():
@@ -195,7 +207,7 @@ def _coop_prologue(tr, spec, slots, role, X, I, qd, u, g, demand_order=True):
                     state["acc"][k] = tr.fma(m, state["umc"][j], state["acc"][k])
         alg.direct_minv(tr, spec, X, I, between=between, on_final=on_final)
         for j in range(n):
-            tr.xch_put(slots.qdd[j], state["acc"][j])
+            tr.xch_put(out_slots[j], state["acc"][j])
         tr.barrier()
     else:
         c = alg.rnea(tr, spec, X, I, qd, None, g)[0]
@@ -206,6 +218,8 @@ def _coop_prologue(tr, spec, slots, role, X, I, qd, u, g, demand_order=True):
                 tr.anchor(c[j])
         tr.barrier()
         tr.barrier()
+    if two:
+        return [tr.xch_get(slots.qdd[j]) + tr.xch_get(slots.qdd2[j]) for j in range(n)]
     return [tr.xch_get(slots.qdd[j]) for j in range(n)]
 
 

@@ -44,3 +44,23 @@ def test_library_contains_gfx950_code_object():
 def test_missing_library_fails_loudly(tmp_path):
     with pytest.raises(host.GridLibraryError):
         host.GridLibrary("iiwa7", path=str(tmp_path / "nope.so"))
+
+
+def test_stream_argument_mapping():
+    """GridHandle's `stream=` arguments: None -> the handle's own stream (the C ABI's NULL; created non-blocking like the reference's,
+    i.e. NOT ordered with the default stream), 0 -> the default stream as hipStreamLegacy (0 is what
+    torch.cuda.current_stream().cuda_stream reports for PyTorch's default stream, and a NULL pointer would mean "the handle's
+    stream"), anything else unchanged; `default_stream` replaces None (DESIGN.md section 9.2)."""
+    from gridcodegenerator_amd import host
+
+    class H:                     # (no GPU needed: the mapping is a pure function of the handle's default_stream)
+        default_stream = None
+    f = host.GridHandle._stream
+    assert host.HIP_STREAM_LEGACY == 1
+    assert f(H, None) is None and f(H, 0) == host.HIP_STREAM_LEGACY and f(H, 0x7f00dead) == 0x7f00dead
+    H.default_stream = 0
+    assert f(H, None) == host.HIP_STREAM_LEGACY and f(H, 0x1234) == 0x1234
+    H.default_stream = 0x55aa
+    assert f(H, None) == 0x55aa and f(H, 0) == host.HIP_STREAM_LEGACY
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "gridcodegenerator_amd", "helpers", "_runtime_emit.py")).read()
+    assert "hipStreamNonBlocking" in hdr          # init_grid keeps the reference's stream flags: the rule above is needed

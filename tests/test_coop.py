@@ -11,11 +11,12 @@ from gridcodegenerator_amd.emit import cores
 from gridcodegenerator_amd.emit.model import RobotSpec
 
 
-def emulate_block(spec, builder, groups, q, qd, u):
+def emulate_block(spec, builder, groups, q, qd, u, ksplit=None):
     """Interpret the cores of one block on the CPU: the exchange region is a dict that every core reads and writes; three
     sweeps reach the fixed point (Minv and c are published first, then qdd by the producer)."""
     n, K = spec.n, q.shape[0]
     slots = cores.CoopSlots(spec)
+    slots.ksplit = ksplit
     traces = [builder(role, cols, slots) for (role, cols) in groups]
     base = {"gravity": np.full(K, 9.81)}
     for j in range(n):
@@ -42,6 +43,37 @@ def emulate_block(spec, builder, groups, q, qd, u):
                     got[:, half * n * n + n * cols[ci] + r] = o
         xch.update(new)
     return got, traces
+
+
+def test_two_producer_waves_match_oracle(robot_name, robots, tables):
+    """Two producer waves (large robots): both run the backward pass of the Minv recursion (each only the part its columns need),
+    each finishes its own columns of the forward pass and its share of qdd = Minv (u - c); every wave reads qdd as the sum."""
+    from oracle import rbd_oracle as O
+    spec = RobotSpec(robots(robot_name))
+    n, K = spec.n, 4
+    q, qd, u = (a.astype(np.float64) for a in make_inputs(n, K, 23))
+    ref = O.fd_grad(tables(robot_name), q, qd, u)
+    ref = np.concatenate([O.flat_colmajor(ref[:, :, :n]), O.flat_colmajor(ref[:, :, n:])], axis=1)
+    b = [0, n // 4, n // 2, 3 * n // 4, n]
+    groups = [("producer", list(range(b[3], b[4]))), ("producer2", list(range(b[2], b[3]))), ("consumer_c", list(range(b[0], b[1]))),
+              ("consumer", list(range(b[1], b[2])))]
+    builder = lambda role, cols, sl: cores.core_gradient_recompute(spec, "fd", cols=cols, coop=(role, sl))
+    got, traces = emulate_block(spec, builder, groups, q, qd, u, ksplit=(n + 1) // 2)
+    assert relerr(got, ref)[0] < 5e-6
+    slots = cores.CoopSlots(spec)
+    published = []
+    for tr, (role, cols) in zip(traces, groups):
+        dsts = [d for (d, _) in tr.outputs]
+        assert dsts.count("barrier") == 2
+        published.append(set(int(d[4:]) for d in dsts if isinstance(d, str) and d.startswith("xch:")))
+    minv_slots = set(slots.minv.values())
+    assert published[0] & minv_slots and published[1] & minv_slots and not (published[0] & published[1])       # disjoint shares
+    assert (published[0] | published[1]) >= minv_slots                                                        # that cover Minv
+    assert set(slots.qdd) <= published[0] and set(slots.qdd2) <= published[1] and set(slots.c) <= published[2]
+    # each producer's trace keeps only part of the recursion: fewer operations than the single producer's
+    single = builder("producer", [], cores.CoopSlots(spec))
+    s2 = cores.CoopSlots(spec); s2.ksplit = (n + 1) // 2
+    assert all(cores._arith_ops(builder(r, [], s2)) < cores._arith_ops(single) for r in ("producer", "producer2"))
 
 
 @pytest.mark.parametrize("schedule", ["fused", "recompute"])
