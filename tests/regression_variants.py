@@ -16,13 +16,18 @@ VARIANTS = {
     "atlas30_fused": dict(base="atlas30", precision="fp32", gen=dict(grad_schedule="fused", grad_splits=[], allow_unverified=True)),
     "iiwa7_fp64": dict(base="iiwa7", precision="fp64", gen=dict(allow_unverified=True)),
 }
+# not a round-1 failure but the same regime taken further: all-double arithmetic for the 30-joint robot (never built before round 2;
+# tests/test_round1_regressions.py::test_all_double_atlas runs it when the library is present)
+EXTRA = {
+    "atlas30_fp64": dict(base="atlas30", precision="fp64", gen=dict(allow_unverified=True, grad_splits=[4])),
+}
 
 
 def register():
     """Register every variant as a robot (idempotent); returns {name: precision}."""
     from gridcodegenerator_amd import host, robots
-    for name, v in VARIANTS.items():
+    for name, v in list(VARIANTS.items()) + list(EXTRA.items()):
         if name not in robots.REGISTERED_ROBOTS:
             robots.register_robot(name, (lambda b: (lambda: robots.get_robot(b)))(v["base"]))
         host.DEFAULT_GEN_KWARGS[name] = dict(v["gen"])
-    return {name: v["precision"] for name, v in VARIANTS.items()}
+    return {name: v["precision"] for name, v in list(VARIANTS.items()) + list(EXTRA.items())}

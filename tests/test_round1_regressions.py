@@ -125,3 +125,24 @@ def test_round1_c_all_double_arithmetic():
         errs = _check_all(h, T, h.n, 333, 5, tol)
         errs2 = _check_all(h, T, h.n, 4096, 6, tol)
     print("round-1 (c) all-double iiwa-7: %s" % {k: "%.1e" % max(v, errs2[k]) for k, v in errs.items()})
+
+
+@pytest.mark.gpu
+def test_all_double_atlas():
+    """All-double arithmetic for the 30-joint robot (tests/regression_variants.py: EXTRA; a library nobody could build while
+    heavy spillers miscomputed): every output to float rounding, i.e. the forward-dynamics gradient of Atlas-30 within
+    north_star's 1e-6 on every batch -- at the price of a kernel that lives in scratch."""
+    import torch
+    from gridcodegenerator_amd import host
+    from gridcodegenerator_amd.robots import get_robot
+    from oracle import rbd_oracle as O
+    precision, p = _lib("atlas30_fp64")
+    assert torch.cuda.is_available()
+    T = O.RobotTables(get_robot("atlas30"))
+    tol = dict(c=2e-7, Minv=2e-7, qdd=2e-7, dc_du=2e-7, dc_du_qdd=2e-7, df_du=3e-7, df_du_qdd_minv=1.7e-6)
+    with host.GridHandle("atlas30_fp64", precision=precision) as h:
+        h.default_stream = 0
+        assert h.L.compute_dtype == "f64"
+        errs = _check_all(h, T, h.n, 333, 47, tol)      # (seed 47: the batch on which the mixed arithmetic reaches 1.1e-6)
+        errs2 = _check_all(h, T, h.n, 2048, 6, tol)
+    print("all-double Atlas-30: %s" % {k: "%.1e" % max(v, errs2[k]) for k, v in errs.items()})
