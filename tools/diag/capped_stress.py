@@ -14,10 +14,8 @@ h = host.GridHandle(name, precision=precision); n = h.n
 x = np.random.default_rng(9).uniform(-1, 1, (K, 3 * n)).astype(np.float32)
 d_in = torch.from_numpy(x).cuda()
 dID, dFD = host.ALG_ID_DU, host.ALG_FD_DU
-if h.coop_available(dFD):
-    h.set_coop(dFD, 1)
 calls = {dID: h.inverse_dynamics_gradient_device, dFD: h.forward_dynamics_gradient_device}
-seq = [(dID, 1), (dID, 4), (dFD, 1), (dID, 2), (dFD, 4), (dID, 1), (dFD, 2)]
+seq = [(dID, 1), (dID, 4), (dFD, 1), (dID, 2), (dFD, 4), (dID, 1), (dFD, 2)] + ([(dFD, -1)] if h.coop_available(dFD) else [])     # -1: tile-cooperative
 bad_launches = 0
 out = torch.empty((K, 2 * n * n), dtype=torch.float32, device="cuda")
 print("torch.cuda.current_stream().cuda_stream = %#x, default_stream = %#x" % (torch.cuda.current_stream().cuda_stream, torch.cuda.default_stream().cuda_stream), flush=True)
@@ -25,7 +23,9 @@ own = torch.cuda.Stream() if mode == "own" else None
 torch.cuda.synchronize()
 for i in range(N):
     alg, S = seq[i % len(seq)]
-    h.set_split(alg, S)
+    if alg == dFD and h.coop_available(dFD):
+        h.set_coop(dFD, 2 if S < 0 else 1)
+    h.set_split(alg, max(S, 0))
     if own is not None:
         with torch.cuda.stream(own):
             out.fill_(float("nan"))
