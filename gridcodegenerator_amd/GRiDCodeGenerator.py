@@ -80,12 +80,9 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin, Verific
         large = self.spec.n > 12
         # Round 1's failing variants (fp64, fused n > 12, register caps on large robots: DESIGN.md section 9) were spill code inside
         # reduced-EXEC regions (section 9.1); the kernels are branch-free now and the variants are regression-tested on the GPU
-        # (tests/test_round1_regressions.py: all three pass).  What is still refused is what has never been built (all-double
-        # kernels of a large robot) and what reintroduces lane-divergent control flow.
+        # (tests/test_round1_regressions.py: all three pass, and so does an all-double Atlas-30 library with 4 KB of scratch per
+        # lane).  What is still refused is what reintroduces lane-divergent control flow.
         if not allow_unverified:
-            if precision == "fp64" and large:
-                raise ValueError("precision='fp64' is verified on the GPU for robots with n <= 12 only (all-double kernels of a %d-joint "
-                                 "robot have not been built); use 'mixed' or pass allow_unverified=True" % self.spec.n)
             if trig != "fast":
                 raise ValueError("trig=%r inlines the math library's sincos, whose large-argument path is a lane-divergent branch: kernels "
                                  "with such branches are unverified (hipcc placed spill code inside the masked region, DESIGN.md "

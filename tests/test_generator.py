@@ -164,11 +164,8 @@ def test_single_timing_twins_are_emitted(generated):
 
 def test_known_bad_variants_are_refused(robots):
     """What is refused at generation time unless allow_unverified=True: options that reintroduce lane-divergent control flow
-     and all-double kernels of a large robot (never built).  The three round-1 failures (all-double
-    arithmetic on small robots, register caps and the fused schedule on large ones) pass tests/test_round1_regressions.py and are
-    accepted."""
-    with pytest.raises(ValueError, match="fp64"):
-        GRiDCodeGenerator(robots("atlas30"), precision="fp64")
+    (DESIGN.md section 9.1).  The three round-1 failures (all-double arithmetic, register caps and the fused schedule on large
+    robots) pass tests/test_round1_regressions.py and are accepted."""
     with pytest.raises(ValueError, match="lane-divergent"):
         GRiDCodeGenerator(robots("iiwa7"), trig="libm")
     with pytest.raises(ValueError, match="lane-divergent"):
@@ -177,6 +174,7 @@ def test_known_bad_variants_are_refused(robots):
         GRiDCodeGenerator(robots("iiwa7"), experimental={"no_such_knob": 1})
     GRiDCodeGenerator(robots("iiwa7"), grad_schedule="fused", waves_per_simd=2)
     GRiDCodeGenerator(robots("iiwa7"), precision="fp64")
+    GRiDCodeGenerator(robots("atlas30"), precision="fp64")
     GRiDCodeGenerator(robots("atlas30"), waves_per_simd=2)
     GRiDCodeGenerator(robots("atlas30"), grad_schedule="fused", grad_splits=[])
     GRiDCodeGenerator(robots("iiwa7"), trig="libm", allow_unverified=True)
