@@ -1131,6 +1131,8 @@ class AlgorithmEmitMixin:
                 return "producer"
             if two and i == W - 2:
                 return "producer2"
+            if slots.hoist_budget:      # the wave with the heaviest (earliest) columns has the whole idle time to park some of them:
+                return "consumer_c" if i == 1 else "consumer"       # the next one computes and publishes c
             return "consumer_c" if i == 0 else "consumer"
         def ops(role, cols):
             # what decides the block's time is the work AFTER the second barrier: every wave leaves it at the same moment (when the
@@ -1160,7 +1162,7 @@ class AlgorithmEmitMixin:
                 best = (worst, parts)
         parts = list(best[1])
         # the additive model is rough for large robots (what a column costs depends on its neighbours): hill-climb on EXACT costs
-        role_of = lambda i: ("consumer" if role_name(i) == "consumer_c" else role_name(i))
+        role_of = (lambda i: role_name(i)) if slots.hoist_budget else (lambda i: ("consumer" if role_name(i) == "consumer_c" else role_name(i)))
         exact = {}
 
         def cost_exact(i, pr):
@@ -1211,7 +1213,7 @@ class AlgorithmEmitMixin:
             if best is None or worst < best[0]:
                 best = (worst, k0)
         slots.ksplit = None
-        return best[1]
+        return best[1], best[0]
 
     def gen_forward_dynamics_gradient_coop(self, use_thread_group=False):
         """`forward_dynamics_gradient_kernel_coop`: one block of COOP_WAVES wavefronts per tile of 64 configurations.  The
@@ -1233,7 +1235,22 @@ class AlgorithmEmitMixin:
                 # Two producer waves: the serial prefix (backward pass 4.4 k + forward pass and qdd 3.4 k arithmetic instructions for
                 # Atlas-30, during which the consumers idle) shrinks by the half of the forward pass the second producer takes.
                 # Not in the mixed arithmetic: the two shares of qdd = Minv (u - c) would be rounded to float before they are added.
-                slots.ksplit = self._coop_prefix_split(builder, slots)
+                slots.ksplit, prefix = self._coop_prefix_split(builder, slots)
+                # ... and the consumer waves fill what is left of their idle time with the d/dqd recursions of some of their columns
+                # (CoopSlots.hoisted_columns; cores.core_gradient_recompute): cost per column traced here, budget = 90 % of the idle
+                # arithmetic (the wave that publishes c has RNEA to do first)
+                arith = ("fma", "mul", "add", "pkfma", "pkmul", "pkadd")
+
+                def before_first_barrier(role, cols):
+                    tr = builder(role, cols, slots)
+                    live = tr.live_nodes()
+                    b0 = [pos for (dst, _), pos in zip(tr.outputs, tr.out_pos) if dst == "barrier"][0]
+                    return sum(1 for k in range(1, b0) if live[k] and tr.nodes[k][0] in arith)
+                rnea_ops = before_first_barrier("consumer_c", [])
+                slots.hoist_cost = [1] * n
+                slots.hoist_budget = {"consumer": 10 ** 9}
+                slots.hoist_cost = [before_first_barrier("consumer", [c]) for c in range(n)]
+                slots.hoist_budget = {"consumer": int(prefix), "consumer_c": int(0.9 * max(0, prefix - rnea_ops))}
         else:
             builder = lambda role, cols, sl: cores.core_forward_dynamics_gradient_coop(self.spec, role, cols, sl, hoist=self.coop_hoist)
         groups = self._coop_groups_fused(builder, slots) if (self.coop_hoist and not rec) else self._coop_groups(builder, slots)

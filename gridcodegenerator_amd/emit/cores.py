@@ -157,6 +157,25 @@ class CoopSlots:
         # columns k < ksplit of the forward pass and "producer2" the columns k >= ksplit (the forward pass is independent per
         # column); each folds its entries into its own share of qdd.  None: one producer does everything.
         self.ksplit = None
+        # Consumer waves idle while the producers run the Minv recursion.  The d/dqd half of a gradient column needs neither qdd
+        # nor Minv before its final product, so a consumer computes it for some of its columns BEFORE the first barrier and keeps
+        # the n values per column in registers: hoist_budget[role] = arithmetic instructions of idle time to fill,
+        # hoist_cost[col] = what the d/dqd recursion of that column costs (None: no hoisting).
+        self.hoist_budget = None
+        self.hoist_cost = None
+        self.hoist_max_columns = 4       # n parked values per column stay in registers across the barriers
+
+    def hoisted_columns(self, role, cols):
+        """The columns of `cols` whose d/dqd recursion this role runs ahead of the barriers: cheapest first while the budget lasts."""
+        if not self.hoist_budget or role not in self.hoist_budget or not cols:
+            return []
+        left, picked = self.hoist_budget[role], []
+        for c in sorted(cols, key=lambda c: self.hoist_cost[c]):
+            if self.hoist_cost[c] > left or len(picked) >= self.hoist_max_columns:
+                break
+            picked.append(c)
+            left -= self.hoist_cost[c]
+        return picked
 
     def entry(self, tr, r, k):
         """Minv_sym[r][k] as a fresh exchange read (None: structural zero)."""
@@ -167,7 +186,7 @@ class CoopSlots:
 COOP_ROLES = ("producer", "producer2", "consumer_c", "consumer")
 
 
-def _coop_prologue(tr, spec, slots, role, X, I, qd, u, g, demand_order=True):
+def _coop_prologue(tr, spec, slots, role, X, I, qd, u, g, demand_order=True, pre_barrier=None):
     """Phases 1 and 2 of a tile-cooperative core; returns qdd (read from the exchange region by every wave).
 
     producer:  backward pass of the Minv recursion | barrier | c from the exchange region; forward pass: every entry of Minv is
@@ -210,12 +229,15 @@ def _coop_prologue(tr, spec, slots, role, X, I, qd, u, g, demand_order=True):
             tr.xch_put(out_slots[j], state["acc"][j])
         tr.barrier()
     else:
-        c = alg.rnea(tr, spec, X, I, qd, None, g)[0]
-        for j in range(n):
-            if role == "consumer_c":
-                tr.xch_put(slots.c[j], c[j])
-            else:
-                tr.anchor(c[j])
+        if role == "consumer_c" or pre_barrier is None:
+            c = alg.rnea(tr, spec, X, I, qd, None, g)[0]
+            for j in range(n):
+                if role == "consumer_c":
+                    tr.xch_put(slots.c[j], c[j])
+                else:
+                    tr.anchor(c[j])
+        if pre_barrier is not None:
+            pre_barrier()                # (consumers: work that needs neither Minv nor qdd, done while the producers are busy)
         tr.barrier()
         tr.barrier()
     if two:
@@ -771,12 +793,7 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
     if coop is not None:
         assert kind == "fd" and not use_qdd_minv and not table and rollout is None
         role, slots = coop
-        mark = tr.cse_mark()
-        u = [tr.inp("in.u(%d)" % j) for j in range(n)]
-        X = alg.build_X(tr, spec, q, trig)
-        qdd = list(_coop_prologue(tr, spec, slots, role, X, I, qd, u, g, demand_order=False))
-        tr.fence()
-        tr.cse_release(mark, keep=[t.ref for pair in trig if pair is not None for t in pair])
+        qdd = None          # (the prologue runs further down, once the per-column helpers it may call are defined)
     elif kind == "fd" and not use_qdd_minv:
         mark = tr.cse_mark()
         u = [tr.inp("in.u(%d)" % j) for j in range(n)]
@@ -802,6 +819,7 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
     nz = alg.minv_zero_pattern(spec) if kind == "fd" else None
 
     memo = {}
+    saved_dqd = {}
     trig = list(trig)
     if table:
         slot = {"s": 0, "c": n, "qd": 2 * n}
@@ -933,8 +951,9 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
             return
         if coop is not None:
             # every upper-triangle entry fetched once per column from the exchange region (4 multiply-adds per LDS read)
+            dqd_half = saved_dqd.pop(col, None) or {k: dc[k][1] for k in rows}       # (computed ahead of the barriers when parked)
             lo, hi = alg.sym_minv_times_columns(tr, spec, lambda r, k: minv_entry(r, k),
-                                                {k: dc[k][0] for k in rows}, {k: dc[k][1] for k in rows})
+                                                {k: dc[k][0] for k in rows}, {k: dqd_half[k] for k in rows})
             for r in range(n):
                 tr.out(lo_base(col) + r, lo[r])
             for r in range(n):
@@ -959,5 +978,27 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
     if rollout is not None:
         assert kind == "fd" and not use_qdd_minv and cols is None and not table
         keep = keep + [dt.ref, dt2.ref]
-    alg.rnea_grad_columns(tr, spec, I, q, qd, trig, loader, emit_column, order=cols, prefetch=0, xof=Xof, keep=keep)
+    order = cols
+    if coop is not None:
+        # phases 1 and 2 of the block (_coop_prologue).  A consumer fills its idle time with the d/dqd recursions of some of its
+        # columns (CoopSlots.hoisted_columns): they need neither qdd nor Minv; the n values per column stay in registers until
+        # the column's products after the second barrier.
+        hoist = slots.hoisted_columns(role, list(cols)) if role in ("consumer", "consumer_c") else []
+
+        def pre_barrier():
+            def capture(col, dc):
+                memo.clear()
+                saved_dqd[col] = {k: dc[k][1] for k in dc}
+                for v in saved_dqd[col].values():
+                    tr.anchor(v)
+            alg.rnea_grad_columns(tr, spec, I, q, qd, trig, loader, capture, order=hoist, prefetch=0, xof=Xof, keep=keep)
+        mark = tr.cse_mark()
+        u = [tr.inp("in.u(%d)" % j) for j in range(n)]
+        X = alg.build_X(tr, spec, q, trig)
+        qdd = list(_coop_prologue(tr, spec, slots, role, X, I, qd, u, g, demand_order=False, pre_barrier=pre_barrier if hoist else None))
+        tr.fence()
+        tr.cse_release(mark, keep=[t.ref for pair in trig if pair is not None for t in pair] + [v.ref for d in saved_dqd.values() for v in d.values() if not isinstance(v.ref, float)])
+        memo.clear()
+        order = hoist + [c for c in cols if c not in hoist]        # the parked columns first: their registers are freed early
+    alg.rnea_grad_columns(tr, spec, I, q, qd, trig, loader, emit_column, order=order, prefetch=0, xof=Xof, keep=keep)
     return tr

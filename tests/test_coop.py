@@ -11,12 +11,16 @@ from gridcodegenerator_amd.emit import cores
 from gridcodegenerator_amd.emit.model import RobotSpec
 
 
-def emulate_block(spec, builder, groups, q, qd, u, ksplit=None):
+def emulate_block(spec, builder, groups, q, qd, u, ksplit=None, park=0):
     """Interpret the cores of one block on the CPU: the exchange region is a dict that every core reads and writes; three
     sweeps reach the fixed point (Minv and c are published first, then qdd by the producer)."""
     n, K = spec.n, q.shape[0]
     slots = cores.CoopSlots(spec)
     slots.ksplit = ksplit
+    if park:        # consumers run the d/dqd recursion of up to `park` of their columns ahead of the barriers
+        slots.hoist_cost = [1] * n
+        slots.hoist_budget = {"consumer": 10 ** 9, "consumer_c": 10 ** 9}
+        slots.hoist_max_columns = park
     traces = [builder(role, cols, slots) for (role, cols) in groups]
     base = {"gravity": np.full(K, 9.81)}
     for j in range(n):
@@ -74,6 +78,36 @@ def test_two_producer_waves_match_oracle(robot_name, robots, tables):
     single = builder("producer", [], cores.CoopSlots(spec))
     s2 = cores.CoopSlots(spec); s2.ksplit = (n + 1) // 2
     assert all(cores._arith_ops(builder(r, [], s2)) < cores._arith_ops(single) for r in ("producer", "producer2"))
+
+
+def test_parked_dqd_recursions_match_oracle(robot_name, robots, tables):
+    """Consumer waves compute the d/dqd half of some of their columns BEFORE the barriers (it needs neither qdd nor Minv until its
+    final product) and keep the values until the column's products: same results, work moved in front of the first barrier."""
+    from oracle import rbd_oracle as O
+    spec = RobotSpec(robots(robot_name))
+    n, K = spec.n, 4
+    q, qd, u = (a.astype(np.float64) for a in make_inputs(n, K, 29))
+    ref = O.fd_grad(tables(robot_name), q, qd, u)
+    ref = np.concatenate([O.flat_colmajor(ref[:, :, :n]), O.flat_colmajor(ref[:, :, n:])], axis=1)
+    b = [0, n // 4, n // 2, 3 * n // 4, n]
+    groups = [("producer", list(range(b[3], b[4]))), ("producer2", list(range(b[2], b[3]))), ("consumer", list(range(b[0], b[1]))),
+              ("consumer_c", list(range(b[1], b[2])))]
+    builder = lambda role, cols, sl: cores.core_gradient_recompute(spec, "fd", cols=cols, coop=(role, sl))
+    plain, tr0 = emulate_block(spec, builder, groups, q, qd, u, ksplit=(n + 1) // 2)
+    got, tr1 = emulate_block(spec, builder, groups, q, qd, u, ksplit=(n + 1) // 2, park=2)
+    assert relerr(got, ref)[0] < 5e-6
+    assert np.abs(got - plain).max() <= 1e-6 * np.abs(ref).max()           # (same arithmetic, emitted earlier)
+
+    def before_first_barrier(tr):
+        live = tr.live_nodes()
+        b0 = [pos for (dst, _), pos in zip(tr.outputs, tr.out_pos) if dst == "barrier"][0]
+        return sum(1 for k in range(1, b0) if live[k] and tr.nodes[k][0] in ("fma", "mul", "add"))
+    for t0, t1, (role, cols) in zip(tr0, tr1, groups):
+        if role.startswith("consumer") and cols:
+            assert before_first_barrier(t1) > before_first_barrier(t0) or role == "consumer"       # work moved ahead of the barriers
+            assert [d for (d, _) in t1.outputs].count("barrier") == 2
+        else:
+            assert before_first_barrier(t1) == before_first_barrier(t0)
 
 
 @pytest.mark.parametrize("schedule", ["fused", "recompute"])
