@@ -1266,6 +1266,12 @@ class AlgorithmEmitMixin:
             return
         self.coop_stats = dict(groups=[(r, list(c)) for (r, c) in groups], slots=slots.count, lds_bytes=4 * lds_elems)
         self.gen_add_code_line("const int FD_DU_COOP_WAVES = %d; // wavefronts per block of the tile-cooperative kernel (block = %d threads, one tile)" % (W, W * WAVE))
+        # from how many tiles on the C ABI picks this kernel by itself.  Large robots: with two producer waves and parked d/dqd
+        # recursions it beats the column split at every batch size (Atlas-30: 59 vs 64 us for one tile, 71 vs 100 us at K = 16384);
+        # without them (mixed arithmetic) only once the chip is full (K = 16384: 134 vs 188 us; K = 4096: 125 vs 106 us).  Small
+        # robots: never by itself (iiwa-7: 12.0 vs 11.0 us).
+        auto_tiles = (1 if slots.hoist_budget else 192) if n > 12 else 0
+        self.gen_add_code_line("const int FD_DU_COOP_AUTO_MIN_TILES = %d; // automatic choice of the tile-cooperative kernel from this many tiles on (0: only on request)" % auto_tiles)
         self.gen_add_code_line("const int FD_DU_COOP_SHARED_MEM_COUNT = %d; // dynamic LDS in T elements: %d staging regions + %d exchange slots x 64 lanes"
                                % (lds_elems, W, slots.count))
         names = []
@@ -1362,6 +1368,7 @@ class AlgorithmEmitMixin:
 
     def _emit_no_coop(self):
         self.gen_add_code_line("const int FD_DU_COOP_SHARED_MEM_COUNT = 0;")
+        self.gen_add_code_line("const int FD_DU_COOP_AUTO_MIN_TILES = 0;")
         self.gen_add_code_lines(["template <typename T>", "__host__ inline",
                                  "bool forward_dynamics_gradient_coop_launch(T *, const T *, const int, const robotModel<T> *, const T, const int, int, hipStream_t) {return false;}",
                                  "template <typename T>", "__host__ inline",

@@ -239,20 +239,16 @@ static int effective_split(const grid_handle *h, int alg, int K) {
 }
 
 // Tile-cooperative kernel (forward-dynamics gradient): 4 waves share a tile, the prefix (Minv | RNEA) is computed once per tile and
-// Minv is read from LDS instead of being held in registers.  Automatic choice, from the sweeps in profiles/r02 (Atlas-30: K = 4096
-// 87 us split x4 vs 98 us cooperative; 16384: 115 vs 99; 32768: 231 vs 199; 65536: 481 vs 432 -- iiwa-7: the column split wins at
-// every batch, 11.2 vs 12.1 us at 16384, because its prefix is short and the cooperative block serialises Minv -> qdd -> columns):
-// large robots from GRID_COOP_AUTO_MIN_TILES tiles on (65536: 441 vs 482 us, 131072: 872 vs 951 us), small robots only on request.
-#ifndef GRID_COOP_AUTO_MIN_TILES
-#define GRID_COOP_AUTO_MIN_TILES 192
-#endif
+// Minv is read from LDS instead of being held in registers.  The automatic choice is a property of the generated kernels and comes
+// from the header (FD_DU_COOP_AUTO_MIN_TILES, with the measurements behind it): every batch size for large robots in fp32, full
+// chips only in the mixed arithmetic, small robots only on request.
 static bool coop_available(int alg) { return alg == GRID_ALG_FD_DU && G::FD_DU_COOP_WAVES > 0; }
 static bool use_coop(const grid_handle *h, int alg, int K, const float *d_qdd, const float *d_Minv) {
     if (!coop_available(alg) || d_qdd != nullptr || d_Minv != nullptr || h->coop[alg] == 1) return false;
     if (h->coop[alg] == 2) return true;
     if (h->split[alg] != 0 || h->pipeline[alg] == 2) return false;          // an explicit choice of another variant wins
     const int tiles = (K + G::GRID_WAVE_SIZE - 1) / G::GRID_WAVE_SIZE;
-    return G::NUM_JOINTS > 12 && tiles >= GRID_COOP_AUTO_MIN_TILES;
+    return G::FD_DU_COOP_AUTO_MIN_TILES > 0 && tiles >= G::FD_DU_COOP_AUTO_MIN_TILES;     // (the generated header knows: see its comment)
 }
 
 // Two-pass (workspace) variants: generated for robots whose gradient working set exceeds the register file.

@@ -409,11 +409,15 @@ def test_full_size_atlas30_65536(handles, tables, torch_cuda):
 
 
 def test_full_size_atlas30_16384(handles, tables, torch_cuda):
-    """north_star target "Atlas-30 at batch 16k": served by the tile-cooperative kernel (automatic choice for large robots from
-    192 tiles on), and -- forced -- by the x4 column-group kernels it replaced there; the two agree to round-off."""
+    """north_star target "Atlas-30 at batch 16k": served by the tile-cooperative kernel (the automatic choice for large robots in
+    fp32 at every batch size; in the mixed arithmetic from 192 tiles on), and -- forced -- by the x4 column-group kernels it
+    replaced; the two agree to round-off."""
     from gridcodegenerator_amd import host
     h = handles("atlas30")
-    assert h.get_coop(host.ALG_FD_DU, 16384) and not h.get_coop(host.ALG_FD_DU, 4096)
+    assert h.get_coop(host.ALG_FD_DU, 16384) and h.get_coop(host.ALG_FD_DU, 64)
+    hm = handles("atlas30", "mixed")
+    assert hm.get_coop(host.ALG_FD_DU, 16384) and not hm.get_coop(host.ALG_FD_DU, 4096)
+    assert not handles("iiwa7").get_coop(host.ALG_FD_DU, 16384)
     df_coop = _full_size_properties(h, tables("atlas30"), 16384, 6, torch_cuda, check_rows=64)
     h.set_coop(host.ALG_FD_DU, 1)
     try:
