@@ -1231,11 +1231,17 @@ class AlgorithmEmitMixin:
         rec = (self.grad_schedule == "recompute")
         if rec:
             builder = lambda role, cols, sl: cores.core_gradient_recompute(self.spec, "fd", cols=cols, coop=(role, sl))
-            if n > 12 and self.precision != "mixed":
+            if n > 12:
                 # Two producer waves: the serial prefix (backward pass 4.4 k + forward pass and qdd 3.4 k arithmetic instructions for
                 # Atlas-30, during which the consumers idle) shrinks by the half of the forward pass the second producer takes.
                 # Not in the mixed arithmetic: the two shares of qdd = Minv (u - c) would be rounded to float before they are added.
-                slots.ksplit, prefix = self._coop_prefix_split(builder, slots)
+                if self.precision != "mixed":
+                    slots.ksplit, prefix = self._coop_prefix_split(builder, slots)
+                else:       # one producer: its whole recursion (up to the second barrier) is the consumers' idle time
+                    ptr = builder("producer", [], slots)
+                    plive = ptr.live_nodes()
+                    pb = [pos for (dst, _), pos in zip(ptr.outputs, ptr.out_pos) if dst == "barrier"]
+                    prefix = sum(1 for k in range(1, pb[1]) if plive[k] and ptr.nodes[k][0] in ("fma", "mul", "add", "pkfma", "pkmul", "pkadd"))
                 # ... and the consumer waves fill what is left of their idle time with the d/dqd recursions of some of their columns
                 # (CoopSlots.hoisted_columns; cores.core_gradient_recompute): cost per column traced here, budget = 90 % of the idle
                 # arithmetic (the wave that publishes c has RNEA to do first)
@@ -1270,7 +1276,7 @@ class AlgorithmEmitMixin:
         # recursions it beats the column split at every batch size (Atlas-30: 59 vs 64 us for one tile, 71 vs 100 us at K = 16384);
         # without them (mixed arithmetic) only once the chip is full (K = 16384: 134 vs 188 us; K = 4096: 125 vs 106 us).  Small
         # robots: never by itself (iiwa-7: 12.0 vs 11.0 us).
-        auto_tiles = (1 if slots.hoist_budget else 192) if n > 12 else 0
+        auto_tiles = (1 if slots.ksplit is not None else 192) if n > 12 else 0
         self.gen_add_code_line("const int FD_DU_COOP_AUTO_MIN_TILES = %d; // automatic choice of the tile-cooperative kernel from this many tiles on (0: only on request)" % auto_tiles)
         self.gen_add_code_line("const int FD_DU_COOP_SHARED_MEM_COUNT = %d; // dynamic LDS in T elements: %d staging regions + %d exchange slots x 64 lanes"
                                % (lds_elems, W, slots.count))
