@@ -248,6 +248,7 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin, Verific
         self.gen_inverse_dynamics_gradient(use_thread_group)
         self.gen_forward_dynamics_gradient(use_thread_group)
         self.gen_forward_dynamics_gradient_coop(use_thread_group)
+        self.gen_forward_dynamics_gradient_host()        # (after the cooperative kernel, which the wrappers dispatch for large robots)
         self.gen_forward_dynamics_gradient_rollout(use_thread_group)
         self.gen_init_close_grid()
         self.gen_add_end_control_flow()

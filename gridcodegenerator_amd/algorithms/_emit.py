@@ -559,8 +559,10 @@ class AlgorithmEmitMixin:
             if single:
                 self.gen_add_code_line("struct timespec start, end; clock_gettime(CLOCK_MONOTONIC,&start);")
             for line in launches:
+                if single and "@S" in line:
+                    continue             # (the latency twins always time the reference-named kernel)
                 line = line.replace("_kernel<T>@L", "_kernel_single_timing<T>@L") if single else line
-                self.gen_add_code_line(line.replace("@L", "<<<blocks,threads,lds_bytes,%s>>>" % stream))
+                self.gen_add_code_line(line.replace("@L", "<<<blocks,threads,lds_bytes,%s>>>" % stream).replace("@S", stream))
             self.gen_add_code_line("gpuErrchk(hipGetLastError());")
             if mode != "launch":
                 self.gen_add_code_line("gpuErrchk(hipDeviceSynchronize());")
@@ -958,6 +960,10 @@ class AlgorithmEmitMixin:
             return lines
         launches = [
             "if (USE_QDD_MINV_FLAG) {forward_dynamics_gradient_kernel<T>@L(hd_data->d_df_du,hd_data->d_q_qd_u,stride_q_qd,hd_data->d_qdd,hd_data->d_Minv,d_robotModel,gravity,num_timesteps);}",
+            # the reference-named wrappers serve the reference's callers: where the tile-cooperative kernel is the faster one
+            # (FD_DU_COOP_AUTO_MIN_TILES: large robots) they launch it -- same outputs to round-off, blocks/threads then unused
+            "else if (FD_DU_COOP_AUTO_MIN_TILES > 0 && (num_timesteps + GRID_WAVE_SIZE - 1)/GRID_WAVE_SIZE >= FD_DU_COOP_AUTO_MIN_TILES && "
+            "forward_dynamics_gradient_coop_launch<T>(hd_data->d_df_du,hd_data->d_q_qd_u,stride_q_qd,d_robotModel,gravity,num_timesteps,0,@S)) {}",
             "else                   {forward_dynamics_gradient_kernel<T>@L(hd_data->d_df_du,hd_data->d_q_qd_u,stride_q_qd,d_robotModel,gravity,num_timesteps);}"]
         post = ["// finally transfer the result back",
                 "gpuErrchk(hipMemcpy(hd_data->h_df_du,hd_data->d_df_du,NUM_JOINTS*2*NUM_JOINTS*num_timesteps*sizeof(T),hipMemcpyDeviceToHost));",
@@ -994,7 +1000,8 @@ class AlgorithmEmitMixin:
                                        ("q_qd_u", 3 * n, "stride_q_qd_u"), False)
         else:
             self._emit_no_pipeline("FD_DU", "forward_dynamics_gradient", "df_du", ("q_qd_u", 3 * n, "stride_q_qd_u"))
-        self.gen_forward_dynamics_gradient_host()
+        # (the host wrappers follow the tile-cooperative kernel: GRiDCodeGenerator.gen_all_code -- they dispatch it where it is the
+        # faster kernel)
 
     # ------------------------------------------------------------------------------------------
     # rollout consumer of the forward-dynamics gradient
@@ -1277,6 +1284,8 @@ class AlgorithmEmitMixin:
         # without them (mixed arithmetic) only once the chip is full (K = 16384: 134 vs 188 us; K = 4096: 125 vs 106 us).  Small
         # robots: never by itself (iiwa-7: 12.0 vs 11.0 us).
         auto_tiles = (1 if slots.ksplit is not None else 192) if n > 12 else 0
+        if self.precision == "fp64":
+            auto_tiles = 0          # (the exchange region holds T = float: an all-double build keeps to its all-double kernels by itself)
         self.gen_add_code_line("const int FD_DU_COOP_AUTO_MIN_TILES = %d; // automatic choice of the tile-cooperative kernel from this many tiles on (0: only on request)" % auto_tiles)
         self.gen_add_code_line("const int FD_DU_COOP_SHARED_MEM_COUNT = %d; // dynamic LDS in T elements: %d staging regions + %d exchange slots x 64 lanes"
                                % (lds_elems, W, slots.count))
