@@ -343,7 +343,11 @@ static int dev_prep(grid_handle *h, const void *d_out, const void *d_in, int K, 
     if (e != hipSuccess) { gpuAssert(e, __FILE__, __LINE__); return grid_fail(who); }
     return 0;
 }
-static inline hipStream_t pick_stream(grid_handle *h, void *stream) { return stream ? (hipStream_t)stream : h->streams[0]; }
+// stream == NULL is HIP's default stream: ordered with everything the caller has queued on it (and on every blocking stream), so a
+// caller that fills its buffers on the default stream and launches with NULL needs no synchronisation.  The handle's own
+// non-blocking streams (init_grid: three, descending priority, NOT ordered with the default stream) serve the host-buffer wrappers
+// and are handed out by grid_stream() to callers that want them.
+static inline hipStream_t pick_stream(grid_handle *h, void *stream) { (void)h; return (hipStream_t)stream; }
 
 int grid_inverse_dynamics_device(grid_handle *h, float *d_c, const float *d_q_qd, int stride_q_qd, const float *d_qdd,
                                  int K, float gravity, int blocks, int threads, void *stream) {
@@ -429,6 +433,11 @@ int grid_set_pipeline(grid_handle *h, int alg, int mode) {
     if (mode == 2 && workspace_count(alg) == 0) { g_last_error = "grid_set_pipeline: no two-pass variant was generated for this robot/algorithm"; return -1; }
     h->pipeline[alg] = mode;
     return 0;
+}
+
+void *grid_stream(grid_handle *h, int index) {
+    if (h == nullptr || index < 0 || index >= 3) { g_last_error = "grid_stream: bad arguments"; return nullptr; }
+    return (void *)h->streams[index];
 }
 
 int grid_synchronize(grid_handle *h, void *stream) {

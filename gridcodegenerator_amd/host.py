@@ -29,7 +29,8 @@ CSRC = os.path.join(PKG_DIR, "csrc", "grid_capi.hip")
 KERNEL_INST_SRC = os.path.join(PKG_DIR, "csrc", "grid_kernel_inst.hip")
 INCLUDE_DIR = os.path.join(REPO_DIR, "include")
 ARCH = "gfx950"
-# arithmetic variants whose kernels pass the GPU parity tests (precision="fp64" is refused by the generator)
+# arithmetic variants that ship (libgrid_<robot>_<precision>.so built by __graft_entry__.build()) and that bench.py offers; the
+# all-double arithmetic (precision="fp64") is accepted by the generator and verified on the GPU as a regression variant only
 VERIFIED_PRECISIONS = ("fp32", "mixed")
 DEFAULT_PRECISION = "fp32"
 
@@ -444,6 +445,7 @@ CAPI_SIGNATURES = [
     ("grid_inverse_dynamics_gradient_device", ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, _vp]),
     ("grid_forward_dynamics_gradient_device", ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, _vp]),
     ("grid_synchronize", ctypes.c_int, [_vp, _vp]),
+    ("grid_stream", _vp, [_vp, ctypes.c_int]),
     ("grid_rollout_row_count", ctypes.c_int, []),
     ("grid_forward_dynamics_gradient_rollout_device", ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                                                      ctypes.c_int, ctypes.c_int, _vp]),
@@ -523,7 +525,6 @@ def _fp(a):
     return a.ctypes.data_as(_c_float_p)
 
 
-HIP_STREAM_LEGACY = 1      # hipStreamLegacy ((hipStream_t)1): the default (NULL) stream as an explicit handle
 
 
 class GridHandle:
@@ -535,23 +536,27 @@ class GridHandle:
         self._h = _vp()
         self.L.check(self.L.lib.grid_init(int(device), ctypes.byref(self._h)), "grid_init")
         self.max_timesteps = 0
-        # stream used by the device-pointer methods when none is passed: None = the handle's own first stream (the C ABI's NULL).
-        # NOTE: like the reference's init_grid this stream is created NON-BLOCKING, i.e. it is NOT ordered with work on the default
-        # stream (PyTorch's default stream included).  Set `default_stream = 0` (or pass stream=...) to launch on the default stream.
-        self.default_stream = None
+        # stream used by the device-pointer methods when none is passed: 0 = HIP's default stream (what
+        # `torch.cuda.current_stream().cuda_stream` reports for PyTorch's default stream), so a launch is ordered with the torch
+        # work that produced its inputs.  The handle's own non-blocking streams (the reference's init_grid streams, NOT ordered
+        # with the default stream) are available from own_stream().
+        self.default_stream = 0
         if max_timesteps:
             self.alloc(max_timesteps)
 
     def _stream(self, stream):
-        """The `stream` argument of the device-pointer methods -> what the C ABI gets.  None: `default_stream` (None there: the
-        handle's own non-blocking stream).  0: the default (NULL) stream -- this is what `torch.cuda.current_stream().cuda_stream`
-        reports for PyTorch's default stream -- passed on as hipStreamLegacy, because a NULL pointer means "the handle's stream"
-        to the C ABI.  Anything else: that stream handle."""
+        """The `stream` argument of the device-pointer methods -> what the C ABI gets.  None: `default_stream`.  0 (or None
+        there): HIP's default stream, the C ABI's NULL.  Anything else: that stream handle."""
         if stream is None:
             stream = self.default_stream
-        if stream is None:
-            return None
-        return HIP_STREAM_LEGACY if int(stream) == 0 else int(stream)
+        return None if (stream is None or int(stream) == 0) else int(stream)
+
+    def own_stream(self, index=0):
+        """One of the handle's own three non-blocking streams (init_grid<T>()) as an integer handle usable as `stream=`."""
+        p = self.L.lib.grid_stream(self._h, int(index))
+        if not p:
+            raise GridLibraryError("grid_stream: " + self.L.last_error())
+        return int(p)
 
     # lifecycle ------------------------------------------------------------------------------------
     def alloc(self, max_timesteps):

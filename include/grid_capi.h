@@ -61,7 +61,12 @@ int grid_forward_dynamics_gradient(grid_handle *h, const float *h_q_qd_u, const 
 /* ---- device-pointer calls = the kernels themselves (reference mode 2, `_compute_only`), asynchronous ----
  * Arguments mirror the __global__ signatures: _inverse_dynamics.py:365-369, _direct_minv.py:414, _forward_dynamics.py:151-152,
  * _inverse_dynamics_gradient.py:703-707, _forward_dynamics_gradient.py:117-125.
- * blocks/threads <= 0 selects the suggested launch shape; stream == NULL uses the handle's first stream.
+ * blocks/threads <= 0 selects the suggested launch shape.
+ * stream == NULL is HIP's default stream, i.e. the launch is ORDERED with whatever the caller queued before it on the default
+ * stream (hipMemcpy, a torch fill, ...): no synchronisation is needed between producing the inputs there and launching.  Any
+ * other value is a hipStream_t.  The handle's own streams -- created by init_grid exactly as the reference creates them, with
+ * priorities and hipStreamNonBlocking (GRiDCodeGenerator.py:182-188), hence NOT ordered with the default stream -- are used by
+ * the host-buffer calls above and can be had from grid_stream(h, 0..2) by a caller that orders its own work on them.
  */
 int grid_inverse_dynamics_device(grid_handle *h, float *d_c, const float *d_q_qd, int stride_q_qd, const float *d_qdd,
                                  int num_timesteps, float gravity, int blocks, int threads, void *stream);
@@ -75,6 +80,8 @@ int grid_forward_dynamics_gradient_device(grid_handle *h, float *d_df_du, const 
                                           const float *d_qdd, const float *d_Minv,
                                           int num_timesteps, float gravity, int blocks, int threads, void *stream);
 int grid_synchronize(grid_handle *h, void *stream);
+/* the handle's own non-blocking streams (init_grid<T>(): three, descending priority); NULL for a bad index */
+void *grid_stream(grid_handle *h, int index);
 
 /* ---- rollout consumer of the forward-dynamics gradient (no reference kernel; the reference ships the `_device` tier for
  * exactly this use, README.md:26-29, algorithms/_forward_dynamics_gradient.py:59-99) ----
@@ -101,7 +108,8 @@ int grid_get_split(grid_handle *h, int alg, int num_timesteps);
  * One block of 4 wavefronts per tile of 64 configurations: one wave runs the Minv recursion while the others run RNEA, the
  * results cross through LDS, then every wave differentiates its own group of columns.  Unlike the column-split kernels the
  * shared prefix is computed ONCE per tile.  grid_coop_available: 1 if the generator emitted it for `alg` (GRID_ALG_FD_DU).
- * grid_set_coop: 0 = automatic (default: large robots from 192 tiles on, measured policy), 1 = never, 2 = always.
+ * grid_set_coop: 0 = automatic (default: FD_DU_COOP_AUTO_MIN_TILES of the generated header -- every batch size for large robots in
+ * fp32, from 192 tiles on in the mixed arithmetic, never for small robots), 1 = never, 2 = always.
  * grid_get_coop: 1 if a call with `num_timesteps` would dispatch it (it takes precedence over the column split). */
 int grid_coop_available(int alg);
 int grid_set_coop(grid_handle *h, int alg, int mode);

@@ -17,7 +17,6 @@ for robot in robots:
     if not os.environ.get("GRID_USE_PREBUILT"):          # (experiments ship a prebuilt library that the build guard would refuse)
         host.build_library(robot, precision)
     h = host.GridHandle(robot, precision=precision)
-    h.default_stream = 0
     n = h.n
     T = O.RobotTables(get_robot(robot))
     for (K, seed) in ((201, 31), (2048, 77)):

@@ -47,20 +47,20 @@ def test_missing_library_fails_loudly(tmp_path):
 
 
 def test_stream_argument_mapping():
-    """GridHandle's `stream=` arguments: None -> the handle's own stream (the C ABI's NULL; created non-blocking like the reference's,
-    i.e. NOT ordered with the default stream), 0 -> the default stream as hipStreamLegacy (0 is what
-    torch.cuda.current_stream().cuda_stream reports for PyTorch's default stream, and a NULL pointer would mean "the handle's
-    stream"), anything else unchanged; `default_stream` replaces None (DESIGN.md section 9.2)."""
+    """GridHandle's `stream=` arguments: None -> `default_stream`, whose default is 0 = HIP's default stream = the C ABI's NULL
+    (0 is what torch.cuda.current_stream().cuda_stream reports for PyTorch's default stream: a launch is then ordered with the
+    torch work that produced its inputs); anything else unchanged.  The handle's own non-blocking streams are not what NULL
+    means any more (that default raced with prefills); they come from grid_stream()."""
     from gridcodegenerator_amd import host
 
     class H:                     # (no GPU needed: the mapping is a pure function of the handle's default_stream)
-        default_stream = None
+        default_stream = 0
     f = host.GridHandle._stream
-    assert host.HIP_STREAM_LEGACY == 1
-    assert f(H, None) is None and f(H, 0) == host.HIP_STREAM_LEGACY and f(H, 0x7f00dead) == 0x7f00dead
-    H.default_stream = 0
-    assert f(H, None) == host.HIP_STREAM_LEGACY and f(H, 0x1234) == 0x1234
+    assert f(H, None) is None and f(H, 0) is None and f(H, 0x7f00dead) == 0x7f00dead
     H.default_stream = 0x55aa
-    assert f(H, None) == 0x55aa and f(H, 0) == host.HIP_STREAM_LEGACY
-    hdr = open(os.path.join(os.path.dirname(__file__), "..", "gridcodegenerator_amd", "helpers", "_runtime_emit.py")).read()
-    assert "hipStreamNonBlocking" in hdr          # init_grid keeps the reference's stream flags: the rule above is needed
+    assert f(H, None) == 0x55aa and f(H, 0) is None
+    H.default_stream = None
+    assert f(H, None) is None
+    capi = open(os.path.join(REPO, "gridcodegenerator_amd", "csrc", "grid_capi.hip")).read()
+    assert "return (hipStream_t)stream;" in capi and "h->streams[0]" not in capi.split("pick_stream")[1].split("}")[0]
+    assert "grid_stream" in declared_symbols()

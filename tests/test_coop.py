@@ -166,7 +166,6 @@ def test_coop_kernel_on_gpu(robot, tables):
     host.build_library(robot, host.DEFAULT_PRECISION)
     T = tables(robot)
     with host.GridHandle(robot, device=0, precision=host.DEFAULT_PRECISION) as h:
-        h.default_stream = 0      # PyTorch's default stream: the handle's own stream is non-blocking, i.e. not ordered with torch's fills / uploads
         assert h.coop_available(host.ALG_FD_DU)
         n = h.n
         for K in (1, 70, 333):
@@ -202,7 +201,6 @@ def test_coop_kernel_full_size_iiwa7_16384(tables):
     from gridcodegenerator_amd import host
     from test_gpu_parity import TOL, oracle_all, pack
     with host.GridHandle("iiwa7", device=0, precision=host.DEFAULT_PRECISION) as h:
-        h.default_stream = 0      # PyTorch's default stream: the handle's own stream is non-blocking, i.e. not ordered with torch's fills / uploads
         n, K = h.n, 16384
         h.set_coop(host.ALG_FD_DU, 2)
         q, qd, u = make_inputs(n, K, 3)

@@ -61,7 +61,6 @@ def handles(torch_cuda):
         if key not in cache:
             host.build_library(robot, precision)      # compiled by build(); rebuilt here only if stale/missing
             cache[key] = host.GridHandle(robot, device=0, precision=precision)
-            cache[key].default_stream = 0      # PyTorch's default stream: the handle's own stream is non-blocking, i.e. NOT ordered with torch's fills / uploads
         return cache[key]
     yield get
     for h in cache.values():

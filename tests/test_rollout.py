@@ -73,7 +73,6 @@ def test_rollout_kernel_on_gpu(robot, K, steps, tables):
     T = tables(robot)
     dt = 0.005
     with host.GridHandle(robot, device=0, precision=host.DEFAULT_PRECISION) as h:
-        h.default_stream = 0      # PyTorch's default stream: the handle's own stream is non-blocking, i.e. not ordered with torch's fills / uploads
         n, row = h.n, h.rollout_row_count()
         assert row == 2 * n * (1 + 3 * n)
         q0, qd0, noise = make_inputs(n, K, 71)

@@ -67,7 +67,6 @@ def test_round1_a_register_capped_atlas_column_groups():
     assert torch.cuda.is_available()
     T = O.RobotTables(get_robot("atlas30"))
     with host.GridHandle("atlas30_capped", precision=precision) as h:
-        h.default_stream = 0      # PyTorch's default stream: the handle's own stream is non-blocking, i.e. not ordered with torch's fills / uploads
         n = h.n
         errs = _check_all(h, T, n, 150, 5, TOL_BY_PRECISION["fp32"]["atlas30"])
         # the failing case itself: every column-split kernel of both gradients at K = 16384, bitwise against the unsplit kernel
@@ -102,7 +101,6 @@ def test_round1_b_fused_schedule_30_joints():
     assert torch.cuda.is_available()
     T = O.RobotTables(get_robot("atlas30"))
     with host.GridHandle("atlas30_fused", precision=precision) as h:
-        h.default_stream = 0      # PyTorch's default stream: the handle's own stream is non-blocking, i.e. not ordered with torch's fills / uploads
         errs = _check_all(h, T, h.n, 150, 5, TOL_BY_PRECISION["fp32"]["atlas30"])
         errs2 = _check_all(h, T, h.n, 2048, 6, TOL_BY_PRECISION["fp32"]["atlas30"])
     print("round-1 (b) fused Atlas-30: %s" % {k: "%.1e" % max(v, errs2[k]) for k, v in errs.items()})
@@ -120,7 +118,6 @@ def test_round1_c_all_double_arithmetic():
     T = O.RobotTables(get_robot("iiwa7"))
     tol = dict(c=1.5e-7, Minv=1.5e-7, qdd=1.5e-7, dc_du=1.5e-7, dc_du_qdd=1.5e-7, df_du=1.5e-7, df_du_qdd_minv=6e-7)
     with host.GridHandle("iiwa7_fp64", precision=precision) as h:
-        h.default_stream = 0      # PyTorch's default stream: the handle's own stream is non-blocking, i.e. not ordered with torch's fills / uploads
         assert h.L.compute_dtype == "f64"
         errs = _check_all(h, T, h.n, 333, 5, tol)
         errs2 = _check_all(h, T, h.n, 4096, 6, tol)
@@ -141,7 +138,6 @@ def test_all_double_atlas():
     T = O.RobotTables(get_robot("atlas30"))
     tol = dict(c=2e-7, Minv=2e-7, qdd=2e-7, dc_du=2e-7, dc_du_qdd=2e-7, df_du=3e-7, df_du_qdd_minv=1.7e-6)
     with host.GridHandle("atlas30_fp64", precision=precision) as h:
-        h.default_stream = 0
         assert h.L.compute_dtype == "f64"
         errs = _check_all(h, T, h.n, 333, 47, tol)      # (seed 47: the batch on which the mixed arithmetic reaches 1.1e-6)
         errs2 = _check_all(h, T, h.n, 2048, 6, tol)

@@ -205,7 +205,6 @@ def test_hand_written_urdf_on_gpu():
     T = O.RobotTables(robot)
     tol = TOL["iiwa7"]                                   # same size and mass range as the built-in 7-joint arm
     with host.GridHandle(name, device=0, precision=host.DEFAULT_PRECISION) as h:
-        h.default_stream = 0      # PyTorch's default stream: the handle's own stream is non-blocking, i.e. not ordered with torch's fills / uploads
         n, K = h.n, 333
         q, qd, u = make_inputs(n, K, 81)
         ref = oracle_all(T, q, qd, u)

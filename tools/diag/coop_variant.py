@@ -12,7 +12,6 @@ for K in (64, 1000, 16384, 65536):
     d_in = torch.from_numpy(x).cuda()
     outs, row = {}, []
     for k, h in hs.items():
-        h.default_stream = 0
         h.set_coop(alg, 2)
         out = torch.zeros((K, 2 * n * n), dtype=torch.float32, device="cuda")
         h.forward_dynamics_gradient_device(out.data_ptr(), d_in.data_ptr(), 3 * n, K); h.synchronize()
