@@ -142,7 +142,7 @@ def committed_traffic(robot, K, kernel, sha):
 class Workload:
     """One robot / batch on this rank's GPU: device-resident inputs and outputs, one handle, the launch closure."""
 
-    def __init__(self, torch, host, robot, K, precision, device, seed, blocks=0, threads=0, split=0, coop=0, streams=1):
+    def __init__(self, torch, host, robot, K, precision, device, seed, blocks=0, threads=0, split=0, coop=0, streams=1, wave=0):
         host.build_library(robot, precision)
         self.host, self.torch, self.robot, self.K, self.precision = host, torch, robot, K, precision
         self.h = host.GridHandle(robot, device=device, precision=precision)
@@ -165,8 +165,12 @@ class Workload:
         self.h.set_split(host.ALG_FD_DU, split)
         if coop:
             self.h.set_coop(host.ALG_FD_DU, coop)
-        self.coop_used = self.h.get_coop(host.ALG_FD_DU, K)          # the tile-cooperative kernel takes precedence over a split
-        self.split_used = 1 if self.coop_used else self.h.get_split(host.ALG_FD_DU, K)
+        if wave:
+            self.h.set_wave(host.ALG_FD_DU, wave)
+        # precedence in the C ABI: wave-per-configuration kernel (small batches of large robots), tile-cooperative kernel, column split
+        self.wave_used = self.h.get_wave(host.ALG_FD_DU, K)
+        self.coop_used = (not self.wave_used) and self.h.get_coop(host.ALG_FD_DU, K)
+        self.split_used = 1 if (self.coop_used or self.wave_used) else self.h.get_split(host.ALG_FD_DU, K)
 
     def step(self):
         i = self.step_no % self.n_streams
@@ -190,8 +194,9 @@ class Workload:
                                      blocks=self.blocks, threads=self.threads, stream=self.stream, reps=reps)
         finite = bool(torch.isfinite(self.d_out).all().item())
         n, K = self.n, self.K
-        kernel = "forward_dynamics_gradient_kernel" + ("_coop" if self.coop_used else ("_split%d" % self.split_used if self.split_used > 1 else ""))
-        attrs = self.h.L.kernel_attributes(host.ALG_FD_DU, split=self.split_used, coop=self.coop_used)
+        kernel = "forward_dynamics_gradient_kernel" + ("_wave" if self.wave_used else "_coop" if self.coop_used else
+                                                       ("_split%d" % self.split_used if self.split_used > 1 else ""))
+        attrs = self.h.L.kernel_attributes(host.ALG_FD_DU, split=self.split_used, coop=self.coop_used, wave=self.wave_used)
         sha = header_sha(self.robot, self.precision)
         traffic, traffic_round = committed_traffic(self.robot, K, kernel, sha)
         alg_bytes = host.algorithmic_bytes(host.ALG_FD_DU, n) * K
@@ -205,7 +210,8 @@ class Workload:
                        "parallelism": "batch-sharded x%d, independent streams, no collective on the data path%s"
                                       % (world, "" if self.n_streams == 1 else "; steps round-robin over %d streams per GPU" % self.n_streams),
                        "launch": {"blocks": self.blocks or "suggested", "threads": self.threads or self.h.L.constants["SUGGESTED_THREADS"],
-                                  "column_split": self.split_used, "tile_cooperative": bool(self.coop_used)},
+                                  "column_split": self.split_used, "tile_cooperative": bool(self.coop_used),
+                                  "wave_per_configuration": bool(self.wave_used)},
                        "kernel": {"name": kernel, "vgprs": attrs["numRegs"], "scratch_bytes_per_lane": attrs["scratch_bytes_per_lane"],
                                   "header_sha": sha},
                        "outputs_finite": finite},

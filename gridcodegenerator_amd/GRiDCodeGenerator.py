@@ -32,11 +32,12 @@ Generation-time knobs that have no reference counterpart are keyword-only:
 from .algorithms._emit import AlgorithmEmitMixin
 from .emit.model import RobotSpec
 from .helpers._runtime_emit import RuntimeEmitMixin
+from .helpers._spatial_emit import SpatialAlgebraEmitMixin
 from .helpers._text import TextMixin
 from .verification import VerificationMixin
 
 
-class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin, VerificationMixin):
+class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, SpatialAlgebraEmitMixin, AlgorithmEmitMixin, VerificationMixin):
     # Experiments that were built, measured on MI355X and rejected (or that exist for the tests only).  Kept reachable through
     # ``experimental={...}`` so the measurements in DESIGN.md stay reproducible; none of them is a supported option.
     EXPERIMENTAL_DEFAULTS = dict(
@@ -47,11 +48,16 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin, Verific
         packed=False,           # (d/dq, d/dqd) recursions as v_pk_fma_f32 pairs: 6777 -> 4818 instructions but 512 registers + spills
         grad_table=False,       # recompute schedule: sin q, cos q, qd, qdd in a per-wave LDS table (Atlas-30: 186 vs 163 us); mixed5 tests it
         split_fences=True,      # scheduling fence after every output store also in the S >= 3 split kernels (without: 13.0 vs 12.0 us)
-        split_sets=False,       # column groups of the S >= 3 splits as arbitrary column sets (12.05 vs 11.46 us at K=16384); mixed5 tests it
+        split_sets=True,        # column groups of the S >= 3 splits of small robots as arbitrary column SETS (exact exhaustive partition on
+                                # the traced costs; iiwa-7 dFD x4: heaviest group 3580 -> 2937 operations), flushed once per half
+                                # (grid_out_colset).  Round 2 flushed them per column and measured them slower at K = 16384 (12.05 vs
+                                # 11.46 us); with one flush per half and a tile's groups in one block: 9.9 vs 10.6 us (profiles/r03)
         fence_stride=1,         # fence after every N-th store instead of every store (12-15 % slower, spills)
         dot_ways=1,             # dot products over w interleaved accumulators (0-4 % slower)
-        split_cap=(2,),         # which split factors are register-capped to two waves per SIMD (small robots only); capping the finer
-                                # splits too was re-measured on the spill-free round-2 kernels: x7 capped 14.8 vs x4 11.1 us at K=16384
+        split_cap=(2, 3, 4),    # which split factors are compiled for two waves per SIMD (<= 256 registers; small robots only).  The 3- and
+                                # 4-way splits run one wave per SIMD at the batch sizes they serve; the cap costs them 2-6 spilled values
+                                # (9.94 vs 9.86 us at K = 16384) and lets a second stream's launch share the chip.  Capping the 7-way split
+                                # so that its waves PAIR UP on SIMDs loses: 14.8 vs 11.1 us (profiles/r03/two_waves_per_simd.md)
         coop_hoist=False,       # tile-cooperative cores of small robots: force everything that does not depend on qdd in front of
                                 # the first barrier (and let the producer go without columns): 12.9 vs 12.1 us at K=16384
     )
@@ -119,6 +125,7 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin, Verific
         self.dot_ways = int(exp["dot_ways"])
         self.split_cap = tuple(int(x) for x in exp["split_cap"])
         self.coop_hoist = bool(exp["coop_hoist"])
+        self.wave_auto_max_k = 1024        # batch sizes up to which large robots use the wave-per-configuration kernel by themselves
         self.kernel_instances = []
         self.split_stats = {}
         self.emit_inner_api = bool(emit_inner_api)
@@ -242,6 +249,7 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin, Verific
         self.gen_init_robotModel()
         self.gen_init_gridData()
         self.gen_load_update_XImats_helpers(use_thread_group)
+        self.gen_spatial_algebra_helpers()       # (after the first algorithm-section function: per-function object-cache keys, host.py)
         self.gen_inverse_dynamics(use_thread_group)
         self.gen_direct_minv(use_thread_group)
         self.gen_forward_dynamics(use_thread_group)
@@ -250,6 +258,7 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, AlgorithmEmitMixin, Verific
         self.gen_forward_dynamics_gradient_coop(use_thread_group)
         self.gen_forward_dynamics_gradient_host()        # (after the cooperative kernel, which the wrappers dispatch for large robots)
         self.gen_forward_dynamics_gradient_rollout(use_thread_group)
+        self.gen_forward_dynamics_gradient_wave(use_thread_group)       # (last: its kernel instance is appended, earlier kernels keep their object-cache keys)
         self.gen_init_close_grid()
         self.gen_add_end_control_flow()
         self.gen_kernel_instance_list()

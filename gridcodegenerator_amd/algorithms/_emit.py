@@ -8,7 +8,8 @@ What is emitted is different in kind: every ``_inner`` / core is one straight-li
 (trace.py), ``_device`` wraps a fused core over lane-private arrays, ``_kernel`` adds the wave-level
 coalesced staging (helpers/_runtime_emit.py) and a grid-stride loop over 64-configuration tiles.
 """
-from ..emit import cores
+from ..emit import cores, wave
+from ..emit.model import SubForest
 
 WAVE = 64
 MAX_IN_PIECE = 64   # inputs wider than this are staged through LDS in pieces (keeps LDS/wave small)
@@ -113,6 +114,12 @@ class AlgorithmEmitMixin:
                 return "GRID_SCHED_FENCE(); in.barrier(); GRID_SCHED_FENCE();"
             if dst == "anchor":
                 return "GRID_KEEP(%s);" % val
+            if dst.startswith("utab:"):
+                return "in.utab_put(%s, (T)(%s));" % (dst[5:], val)
+            if dst.startswith("mput:"):
+                return "in.m_put(%s, (T)(%s));" % (dst[5:], val)
+            if dst == "wsync":
+                return "GRID_SCHED_FENCE(); in.sync(); GRID_SCHED_FENCE();"
         return "out.put(%s, (T)(%s));%s" % (dst, val, fence_after_store())
 
     def _emit_load(self, dst, src, total, stride, piece=MAX_IN_PIECE):
@@ -152,10 +159,12 @@ class AlgorithmEmitMixin:
                  "launch with <<<blocks, SUGGESTED_THREADS, %s_DYNAMIC_SHARED_MEM_COUNT*sizeof(T)>>>; any block shape up to" % alg,
                  "GRID_MAX_THREADS threads is accepted (the dynamic LDS must cover ceil(threads/64) wave regions)"]
         if parts:
-            notes += ["COLUMN-SPLIT variant for small batches: %d column groups %s; block b computes group b %% %d for tile group b / %d,"
-                      % (len(parts), [list(c) for (_, c) in parts], len(parts), len(parts)),
-                      "every group repeats the shared prefix (X(q), Minv, RNEA) -- the SIMDs it uses would otherwise idle.",
-                      "gridDim must be a multiple of %d (use the *_split_launch helper)" % len(parts)]
+            notes += ["COLUMN-SPLIT variant for small batches: %d column groups %s; the grid's whole wavefronts are numbered block-major and"
+                      % (len(parts), [list(c) for (_, c) in parts]),
+                      "wave gw computes group gw %% %d of tile gw / %d (grid_tile_iter): with %d waves per block a tile's groups share a CU."
+                      % (len(parts), len(parts), len(parts)),
+                      "Every group repeats the shared prefix (X(q), Minv, RNEA) -- the SIMDs it uses would otherwise idle.",
+                      "Blocks of whole wavefronts (use the *_split_launch helper)"]
         self.gen_add_func_doc(doc, notes, params, None)
         self.gen_add_code_line("template <typename T, typename C = typename grid_compute<T>::type>")
         # the 2-way split is the one used when the batch fills the chip: cap it at 256 registers so two waves share a SIMD
@@ -211,8 +220,10 @@ class AlgorithmEmitMixin:
                 contiguous = list(cols) == list(range(cols[0], cols[-1] + 1))
                 if not contiguous:
                     assert not direct and 64 * n <= self.lds_per_wave(alg)
-                    self.gen_add_code_line("grid_out_cols<T,%d,%d,%s> out = {s_wave, d_%s, k0, it.lane, it.W, NUM_TIMESTEPS};   // columns %s"
-                                           % (n_out, n, ",".join(str(c) for c in cols), out_name, list(cols)))
+                    # one flush per half when the whole set fits the wave's LDS region, else one per column
+                    sink = "grid_out_colset" if 64 * len0 <= self.lds_per_wave(alg) else "grid_out_cols"
+                    self.gen_add_code_line("%s<T,%d,%d,%s> out = {s_wave, d_%s, k0, it.lane, it.W, NUM_TIMESTEPS};   // columns %s"
+                                           % (sink, n_out, n, ",".join(str(c) for c in cols), out_name, list(cols)))
                 elif direct:
                     self.gen_add_code_line("grid_out_direct<T,%d,%d,%d> out = {d_row};" % (n * cols[0], len0, n * n + n * cols[0]))
                 else:
@@ -492,7 +503,9 @@ class AlgorithmEmitMixin:
         pname, pcount, pstride = primary
         grav = "const T gravity, " if has_gravity else ""
         self.gen_add_func_doc("Launch a column-split variant of %s (asynchronous, on `stream`)" % kernel_base,
-                              ["split must be one of %s_SPLITS; tile_blocks x split blocks of `threads` threads are launched" % alg,
+                              ["split must be one of %s_SPLITS; tiles_in_flight x split wavefronts are launched (the kernel strides over the" % alg,
+                               "remaining tiles), packed into blocks of `threads` threads rounded to whole wavefronts -- 64*split threads put the",
+                               "column groups of a tile on one CU; threads.x == 0: that shape (capped at GRID_MAX_THREADS)",
                                "returns false (and launches nothing) for an unsupported split"], [], None)
         self.gen_add_code_line("const int %s_NUM_SPLITS = %d;" % (alg, len(chosen)))
         self.gen_add_code_line("const int %s_SPLITS[%d] = {%s};" % (alg, max(1, len(chosen)), ",".join(str(S) for (S, _, _) in chosen) or "0"))
@@ -502,13 +515,21 @@ class AlgorithmEmitMixin:
         self.gen_add_code_line("__host__ inline")
         self.gen_add_code_line("bool %s_split_launch(const int split, T *d_%s, const T *d_%s, const int %s, const robotModel<T> *d_robotModel, %sconst int num_timesteps,"
                                % (kernel_base.replace("_kernel", ""), out_name, pname, pstride, grav))
-        self.gen_add_code_line("        int tile_blocks, const dim3 threads, hipStream_t stream) {", True)
-        self.gen_add_code_line("const size_t lds_bytes = grid_lds_bytes<T>(threads, %d);" % self.lds_per_wave(alg))
-        self.gen_add_code_line("if (tile_blocks < 1){tile_blocks = 1;}")
+        self.gen_add_code_line("        int tiles_in_flight, const dim3 threads, hipStream_t stream) {", True)
+        self.gen_add_code_lines([
+            "int nthreads = threads.x*threads.y*threads.z;",
+            "if (nthreads <= 0){nthreads = GRID_WAVE_SIZE*split;}",
+            "nthreads = ((nthreads + GRID_WAVE_SIZE - 1)/GRID_WAVE_SIZE)*GRID_WAVE_SIZE; if (nthreads > GRID_MAX_THREADS){nthreads = GRID_MAX_THREADS;}",
+            "const int waves = nthreads/GRID_WAVE_SIZE;",
+            "const dim3 block(nthreads,1,1);",
+            "const size_t lds_bytes = grid_lds_bytes<T>(block, %d);" % self.lds_per_wave(alg),
+            "if (tiles_in_flight < 1){tiles_in_flight = 1;}",
+            "const dim3 grid((tiles_in_flight*split + waves - 1)/waves,1,1);     // (surplus waves of the last block idle)",
+        ])
         self.gen_add_code_line("switch (split){", True)
         for (S, parts, worst) in chosen:
-            self.gen_add_code_line("case %d: %s_split%d<T><<<dim3(tile_blocks*%d,1,1),threads,lds_bytes,stream>>>(d_%s,d_%s,%s,d_robotModel,%snum_timesteps); return true;"
-                                   % (S, kernel_base, S, S, out_name, pname, pstride, "gravity," if has_gravity else ""))
+            self.gen_add_code_line("case %d: %s_split%d<T><<<grid,block,lds_bytes,stream>>>(d_%s,d_%s,%s,d_robotModel,%snum_timesteps); return true;"
+                                   % (S, kernel_base, S, out_name, pname, pstride, "gravity," if has_gravity else ""))
         self.gen_add_code_line("default: return false;")
         self.gen_add_end_control_flow()
         self.gen_add_end_function()
@@ -1379,6 +1400,134 @@ class AlgorithmEmitMixin:
         self.gen_add_code_line("__host__ inline")
         self.gen_add_code_line("bool forward_dynamics_gradient_coop_attributes(hipFuncAttributes *attr) {", True)
         self.gen_add_code_line("gpuErrchk(hipFuncGetAttributes(attr, reinterpret_cast<const void *>(&forward_dynamics_gradient_kernel_coop<T>))); return true;")
+        self.gen_add_end_function()
+
+    # ------------------------------------------------------------------------------------------
+    # wave-per-configuration forward-dynamics gradient: the lanes of ONE wavefront share a configuration
+    # ------------------------------------------------------------------------------------------
+    def _emit_no_wave(self):
+        self.gen_add_code_line("const int FD_DU_WAVE_WAVES = 0; // no wave-per-configuration kernel for this robot")
+        self.gen_add_code_line("const int FD_DU_WAVE_AUTO_MAX_K = 0;")
+        self.gen_add_code_lines(["template <typename T>", "__host__ inline",
+                                 "bool forward_dynamics_gradient_wave_launch(T *, const T *, const int, const robotModel<T> *, const T, const int, int, hipStream_t) {return false;}",
+                                 "template <typename T>", "__host__ inline",
+                                 "bool forward_dynamics_gradient_wave_attributes(hipFuncAttributes *) {return false;}", ""])
+
+    def gen_forward_dynamics_gradient_wave(self, use_thread_group=False):
+        """`forward_dynamics_gradient_kernel_wave`: one BLOCK per configuration, one wavefront per group of base-rooted trees; the
+        lanes of a wave are the gradient columns (and the Minv columns) of its group -- the small-batch path (SURVEY.md section
+        8(f) rank 2): the reference's block-per-configuration mapping (GRiDCodeGenerator.py:72-83, helpers/_code_generation_helpers.py:
+        41-55) redone for 64-wide wavefronts, with cross-lane traffic through v_readlane broadcasts and wave-local LDS instead of
+        __syncthreads."""
+        n = self.spec.n
+        groups = wave.wave_groups(self.spec) if self.precision != "fp64" else None
+        if not groups:
+            self._emit_no_wave()
+            return
+        W = len(groups)
+        per_wave = 0
+        layout = []
+        for (first, m) in groups:
+            ut = 18 * m
+            utab_elems = 2 * ut + WAVE                 # table + the scratch words the lanes other than 0 write
+            mat_elems = 2 * 32 * m + WAVE              # published matrix (row stride 32) + scratch of the lanes >= m
+            out_elems = WAVE * n                       # output image [64 columns][n rows]
+            layout.append((ut, utab_elems, mat_elems, out_elems))
+            per_wave = max(per_wave, utab_elems + mat_elems + out_elems)
+        self.wave_stats = dict(groups=list(groups), lds_bytes=4 * per_wave * W)
+        self.gen_add_code_line("const int FD_DU_WAVE_WAVES = %d; // wavefronts per block of the wave-per-configuration kernel: one block per configuration, "
+                               "joint groups %s" % (W, [list(range(f, f + m)) for (f, m) in groups]))
+        # batch sizes up to which the C ABI picks this kernel by itself: large robots while the batch leaves most of the chip idle
+        # (one wave per group and configuration; measured against the tile-cooperative kernel in profiles/r03/latency_*.txt);
+        # small robots only on request (iiwa-7: the 7-way column split is faster, see DESIGN.md)
+        self.gen_add_code_line("const int FD_DU_WAVE_AUTO_MAX_K = %d; // automatic choice of the wave-per-configuration kernel up to this batch size (0: only on request)"
+                               % (self.wave_auto_max_k if n > 12 else 0))
+        self.gen_add_code_line("const int FD_DU_WAVE_SHARED_MEM_COUNT = %d; // dynamic LDS of a block in T elements (%d per wave: uniform table, published Minv, output image)"
+                               % (per_wave * W, per_wave))
+        names = []
+        for w, (first, m) in enumerate(groups):
+            cname = "forward_dynamics_gradient_wave_core_w%d" % w
+            tr = wave.core_forward_dynamics_gradient_wave(SubForest(self.spec, first, m))
+            self._emit_core(cname, "Wave-per-configuration forward-dynamics gradient, joints %d..%d: lane l < %d is column l of d/dq, lane %d + l of d/dqd"
+                            % (first, first + m - 1, m, m), tr, order="creation")
+            names.append(cname)
+        self.kernel_instances.append("__global__ void @NS::forward_dynamics_gradient_kernel_wave<T>(T *, const T *, const int, "
+                                     "const @NS::robotModel<T> *, const T, const int);")
+        self.gen_add_func_doc("Computes the gradient of forward dynamics (wave-per-configuration: the 64 lanes of a wavefront share ONE configuration)",
+                              ["launch with EXACTLY %d threads per block and FD_DU_WAVE_SHARED_MEM_COUNT*sizeof(T) of dynamic LDS" % (W * WAVE),
+                               "(use forward_dynamics_gradient_wave_launch); block b computes configuration b, b + gridDim, ...",
+                               "wave w of a block owns the joints %s (base-rooted trees do not interact)" % [list(range(f, f + m)) for (f, m) in groups]],
+                              ["d_df_du is the output buffer, %d values per configuration" % (2 * n * n),
+                               "d_q_qd_u is the input buffer, %d values read per configuration" % (3 * n),
+                               "stride_q_qd_u is the stride between configurations in d_q_qd_u",
+                               "d_robotModel is the pointer to the initialized model specific helpers on the GPU (unused: constants are baked in)",
+                               "gravity is the gravity constant", "NUM_TIMESTEPS is the number of configurations"], None)
+        self.gen_add_code_line("template <typename T, typename C = typename grid_compute<T>::type>")
+        self.gen_add_code_line("__global__ __launch_bounds__(%d)" % (W * WAVE))
+        self.gen_add_code_line("void forward_dynamics_gradient_kernel_wave(T *d_df_du, const T *d_q_qd_u, const int stride_q_qd_u, "
+                               "const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS) {", True)
+        self.gen_add_code_lines([
+            "extern __shared__ __align__(16) unsigned char s_grid_dyn[];",
+            "(void)d_robotModel;",
+            "const int tid = threadIdx.x + blockDim.x*(threadIdx.y + blockDim.y*threadIdx.z);",
+            "const int lane = tid & (GRID_WAVE_SIZE - 1);",
+            "const int wave = __builtin_amdgcn_readfirstlane(tid / GRID_WAVE_SIZE);",
+            "const int nblocks = gridDim.x*gridDim.y*gridDim.z;",
+            "const int bid = blockIdx.x + gridDim.x*(blockIdx.y + gridDim.y*blockIdx.z);",
+            "if (blockDim.x*blockDim.y*blockDim.z != %d){return;}    // (the launcher guarantees it)" % (W * WAVE),
+            "T *s_w = reinterpret_cast<T *>(s_grid_dyn) + wave*%d;" % per_wave,
+            "switch (wave){", ], True)
+        for w, (first, m) in enumerate(groups):
+            ut, utab_elems, mat_elems, out_elems = layout[w]
+            self.gen_add_code_line("case %d: {" % w, True)
+            self.gen_add_code_lines([
+                "const int kcol = lane %% %d;" % m,
+                "T *s_utab = s_w; T *s_mat = s_w + %d; T *s_out = s_w + %d;" % (utab_elems, utab_elems + mat_elems),
+                "T *wput = (lane == 0) ? s_utab : (s_utab + %d + lane);     // only lane 0 writes the table proper" % ut,
+                "T *mput = (lane < %d) ? (s_mat + lane) : (s_mat + %d + lane);   // only the lanes that own a column publish it" % (m, 32 * m),
+                "grid_out_wave<T,%d,%d,%d> out = {s_out, lane};" % (n, first, m),
+                "out.clear();",
+                "for (int k = bid; k < NUM_TIMESTEPS; k += nblocks){", ], True)
+            self.gen_add_code_lines([
+                "const T *row = d_q_qd_u + (size_t)k*stride_q_qd_u;",
+                "const grid_in_wave<T> in = {row[%d + kcol], row[%d + kcol], row[%d + kcol], s_utab, wput, s_mat, mput, lane, kcol, %d};"
+                % (first, n + first, 2 * n + first, m),
+                "%s<T,C>(in, out, gravity);" % names[w],
+                "out.flush(d_df_du + (size_t)k*%d);" % (2 * n * n),
+            ])
+            self.gen_add_end_control_flow()
+            self.gen_add_code_line("break;")
+            self.gen_add_end_control_flow()
+        self.gen_add_code_line("default: break;")
+        self.gen_add_end_control_flow()
+        self.gen_add_end_function()
+        self.gen_add_func_doc("Launch the wave-per-configuration forward-dynamics-gradient kernel (asynchronous, on `stream`)",
+                              ["blocks <= 0: one block per configuration (capped at 8*SUGGESTED_MAX_BLOCKS; larger batches stride)",
+                               "returns false when this robot has no such kernel"], [], None)
+        self.gen_add_code_line("template <typename T>")
+        self.gen_add_code_line("__host__ inline")
+        self.gen_add_code_line("bool forward_dynamics_gradient_wave_launch(T *d_df_du, const T *d_q_qd_u, const int stride_q_qd_u, const robotModel<T> *d_robotModel, "
+                               "const T gravity, const int num_timesteps, int blocks, hipStream_t stream) {", True)
+        self.gen_add_code_lines([
+            "const size_t lds_bytes = (size_t)FD_DU_WAVE_SHARED_MEM_COUNT*sizeof(T);",
+            "static thread_local int configured_device = -1;        // > 64 KiB of dynamic LDS must be enabled once per device",
+            "int dev = 0; gpuErrchk(hipGetDevice(&dev));",
+            "if (lds_bytes > 65536 && configured_device != dev){",
+            "    gpuErrchk(hipFuncSetAttribute(reinterpret_cast<const void *>(&forward_dynamics_gradient_kernel_wave<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));",
+            "    configured_device = dev;",
+            "}",
+            "if (blocks <= 0 || blocks > num_timesteps){blocks = num_timesteps;}",
+            "if (blocks > 8*SUGGESTED_MAX_BLOCKS){blocks = 8*SUGGESTED_MAX_BLOCKS;}",
+            "forward_dynamics_gradient_kernel_wave<T><<<dim3(blocks,1,1),dim3(%d,1,1),lds_bytes,stream>>>(d_df_du,d_q_qd_u,stride_q_qd_u,d_robotModel,gravity,num_timesteps);" % (W * WAVE),
+            "gpuErrchk(hipGetLastError());",
+            "return true;",
+        ])
+        self.gen_add_end_function()
+        self.gen_add_func_doc("hipFuncGetAttributes of the wave-per-configuration kernel", ["returns false when this robot has none"], [], None)
+        self.gen_add_code_line("template <typename T>")
+        self.gen_add_code_line("__host__ inline")
+        self.gen_add_code_line("bool forward_dynamics_gradient_wave_attributes(hipFuncAttributes *attr) {", True)
+        self.gen_add_code_line("gpuErrchk(hipFuncGetAttributes(attr, reinterpret_cast<const void *>(&forward_dynamics_gradient_kernel_wave<T>))); return true;")
         self.gen_add_end_function()
 
     def _emit_no_coop(self):

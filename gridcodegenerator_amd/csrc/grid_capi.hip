@@ -30,6 +30,7 @@ struct grid_handle {
     int split[5];   // per algorithm: 0 = auto, 1 = never split, S = force the S-way column-split kernel
     int pipeline[5];   // per algorithm: 0 = auto (single kernel), 1 = single kernel, 2 = two-pass (workspace) variant
     int coop[5];       // per algorithm: 0 = auto, 1 = never, 2 = always the tile-cooperative kernel (where generated)
+    int wave[5];       // per algorithm: 0 = auto, 1 = never, 2 = always the wave-per-configuration kernel (where generated)
     int unsplit_regs[5];   // registers of the unsplit kernel (hipFuncGetAttributes at init): <= 256 means two waves share a SIMD
     T *d_workspace; size_t workspace_bytes; hipStream_t workspace_stream; bool workspace_busy;
 };
@@ -86,7 +87,7 @@ int grid_init(int device, grid_handle **out) {
     GRID_TRY(hipSetDevice(device), "grid_init: hipSetDevice");
     grid_handle *h = new grid_handle();
     h->device = device; h->hd_data = nullptr; h->max_timesteps = 0;
-    for (int a = 0; a < 5; a++) { h->split[a] = 0; h->pipeline[a] = 0; h->coop[a] = 0; }
+    for (int a = 0; a < 5; a++) { h->split[a] = 0; h->pipeline[a] = 0; h->coop[a] = 0; h->wave[a] = 0; }
     h->d_workspace = nullptr; h->workspace_bytes = 0; h->workspace_stream = nullptr; h->workspace_busy = false;
     for (int a = 0; a < 5; a++) { int attr[4] = {0, 0, 0, 0}; h->unsplit_regs[a] = (grid_kernel_attributes(a, 0, attr) == 0) ? attr[0] : 512; }
     h->d_robotModel = G::init_robotModel<T>();
@@ -246,9 +247,21 @@ static bool coop_available(int alg) { return alg == GRID_ALG_FD_DU && G::FD_DU_C
 static bool use_coop(const grid_handle *h, int alg, int K, const float *d_qdd, const float *d_Minv) {
     if (!coop_available(alg) || d_qdd != nullptr || d_Minv != nullptr || h->coop[alg] == 1) return false;
     if (h->coop[alg] == 2) return true;
-    if (h->split[alg] != 0 || h->pipeline[alg] == 2) return false;          // an explicit choice of another variant wins
+    if (h->split[alg] != 0 || h->pipeline[alg] == 2 || h->wave[alg] == 2) return false;          // an explicit choice of another variant wins
     const int tiles = (K + G::GRID_WAVE_SIZE - 1) / G::GRID_WAVE_SIZE;
     return G::FD_DU_COOP_AUTO_MIN_TILES > 0 && tiles >= G::FD_DU_COOP_AUTO_MIN_TILES;     // (the generated header knows: see its comment)
+}
+
+// Wave-per-configuration kernel (forward-dynamics gradient): one block per configuration, the lanes of a wavefront are the gradient
+// columns of a group of base-rooted trees.  A configuration then takes as long as its longest group's chain ON 64 LANES, not as long as
+// the whole chain on one lane: the small-batch path.  Automatic up to FD_DU_WAVE_AUTO_MAX_K configurations (generated header: large
+// robots; the measurements are quoted there); an explicit choice of another variant wins.
+static bool wave_available(int alg) { return alg == GRID_ALG_FD_DU && G::FD_DU_WAVE_WAVES > 0; }
+static bool use_wave(const grid_handle *h, int alg, int K, const float *d_qdd, const float *d_Minv) {
+    if (!wave_available(alg) || d_qdd != nullptr || d_Minv != nullptr || h->wave[alg] == 1) return false;
+    if (h->wave[alg] == 2) return true;
+    if (h->split[alg] != 0 || h->pipeline[alg] == 2 || h->coop[alg] == 2) return false;
+    return G::FD_DU_WAVE_AUTO_MAX_K > 0 && K <= G::FD_DU_WAVE_AUTO_MAX_K;
 }
 
 // Two-pass (workspace) variants: generated for robots whose gradient working set exceeds the register file.
@@ -277,6 +290,10 @@ static int launch_alg(grid_handle *h, int alg, float *d_out, const float *d_in, 
                       int K, float gravity, int blocks, int threads, hipStream_t s) {
     dim3 b, t;
     launch_shape(K, blocks, threads, &b, &t);
+    if (use_wave(h, alg, K, d_qdd, d_Minv)) {
+        G::forward_dynamics_gradient_wave_launch<T>(d_out, d_in, stride, h->d_robotModel, gravity, K, blocks > 0 ? blocks : 0, s);
+        return grid_check("kernel launch (wave-per-configuration)");
+    }
     if (use_coop(h, alg, K, d_qdd, d_Minv)) {
         G::forward_dynamics_gradient_coop_launch<T>(d_out, d_in, stride, h->d_robotModel, gravity, K, blocks > 0 ? blocks : 0, s);
         return grid_check("kernel launch (tile-cooperative)");
@@ -292,12 +309,22 @@ static int launch_alg(grid_handle *h, int alg, float *d_out, const float *d_in, 
     if ((alg == GRID_ALG_FD_DU || alg == GRID_ALG_ID_DU) && d_qdd == nullptr && d_Minv == nullptr) {
         const int S = effective_split(h, alg, K);
         if (S > 1) {
-            const int nthreads = t.x * t.y * t.z;
-            int tile_blocks = (blocks > 0) ? (int)(b.x * b.y * b.z) : (K + nthreads - 1) / nthreads;
-            if (tile_blocks * S > G::SUGGESTED_MAX_BLOCKS * 4) tile_blocks = (G::SUGGESTED_MAX_BLOCKS * 4) / S;
+            // tiles_in_flight x S wavefronts, packed into blocks of 64*S threads (capped at GRID_MAX_THREADS) unless the caller chose a
+            // block size: the column groups of a tile are then the waves of one block -- one CU, one XCD's L2 for the pieces of
+            // the tile's output rows (profiles/r03: WRITE_SIZE per launch)
+            const int tiles = (K + G::GRID_WAVE_SIZE - 1) / G::GRID_WAVE_SIZE;
+            int tiles_in_flight = (blocks > 0) ? (int)(b.x * b.y * b.z) : tiles;
+            if (tiles_in_flight > tiles) tiles_in_flight = tiles;
+            if (tiles_in_flight * S > G::SUGGESTED_MAX_BLOCKS * 4) tiles_in_flight = (G::SUGGESTED_MAX_BLOCKS * 4) / S;
+            // ... when the launch has more waves than the chip has CUs and every wave is resident at once (one per SIMD).  Fewer waves:
+            // single-wave blocks, one per CU -- a wave alone on a CU is 4-6 % faster (iiwa-7 dFD x4 at K = 4096: 8.7 vs 9.1 us); more:
+            // single-wave blocks again, which the dispatcher back-fills SIMD by SIMD (a 4-wave block of a 512-register kernel needs a
+            // whole free CU).  Measured, iiwa-7 K = 16384: dFD x4 9.9 vs 11.6 us, dID x4 7.1 vs 9.9 us (profiles/r03/exp_iiwa7_column_sets.txt)
+            const long long nwaves = (long long)tiles_in_flight * S;
+            const dim3 tb = (threads > 0) ? t : ((nwaves > GRID_CUS && nwaves <= 4LL * GRID_CUS) ? dim3(0, 1, 1) : dim3(G::GRID_WAVE_SIZE, 1, 1));
             bool ok = (alg == GRID_ALG_FD_DU)
-                ? G::forward_dynamics_gradient_split_launch<T>(S, d_out, d_in, stride, h->d_robotModel, gravity, K, tile_blocks, t, s)
-                : G::inverse_dynamics_gradient_split_launch<T>(S, d_out, d_in, stride, h->d_robotModel, gravity, K, tile_blocks, t, s);
+                ? G::forward_dynamics_gradient_split_launch<T>(S, d_out, d_in, stride, h->d_robotModel, gravity, K, tiles_in_flight, tb, s)
+                : G::inverse_dynamics_gradient_split_launch<T>(S, d_out, d_in, stride, h->d_robotModel, gravity, K, tiles_in_flight, tb, s);
             if (ok) {
                 hipError_t e = hipGetLastError();
                 if (e != hipSuccess) { gpuAssert(e, __FILE__, __LINE__); return grid_fail("kernel launch (split)"); }
@@ -423,6 +450,26 @@ int grid_kernel_attributes_coop(int alg, int *out) {
     hipFuncAttributes a;
     G::forward_dynamics_gradient_coop_attributes<T>(&a);
     if (int rc = grid_check("grid_kernel_attributes_coop")) return rc;
+    out[0] = a.numRegs; out[1] = (int)a.sharedSizeBytes; out[2] = (int)a.localSizeBytes; out[3] = a.maxThreadsPerBlock;
+    return 0;
+}
+
+int grid_wave_available(int alg) { return wave_available(alg) ? 1 : 0; }
+int grid_set_wave(grid_handle *h, int alg, int mode) {
+    if (h == nullptr || alg < 0 || alg > 4 || mode < 0 || mode > 2) { g_last_error = "grid_set_wave: bad arguments"; return -1; }
+    if (mode == 2 && !wave_available(alg)) { g_last_error = "grid_set_wave: no wave-per-configuration kernel was generated for this robot/algorithm"; return -1; }
+    h->wave[alg] = mode;
+    return 0;
+}
+int grid_get_wave(grid_handle *h, int alg, int num_timesteps) {
+    if (h == nullptr || alg < 0 || alg > 4) return -1;
+    return use_wave(h, alg, num_timesteps, nullptr, nullptr) ? 1 : 0;
+}
+int grid_kernel_attributes_wave(int alg, int *out) {
+    if (out == nullptr || !wave_available(alg)) { g_last_error = "grid_kernel_attributes_wave: not available"; return -1; }
+    hipFuncAttributes a;
+    G::forward_dynamics_gradient_wave_attributes<T>(&a);
+    if (int rc = grid_check("grid_kernel_attributes_wave")) return rc;
     out[0] = a.numRegs; out[1] = (int)a.sharedSizeBytes; out[2] = (int)a.localSizeBytes; out[3] = a.maxThreadsPerBlock;
     return 0;
 }

@@ -147,3 +147,34 @@ class RobotSpec:
             out[36 * j:36 * (j + 1)] = Xc.T.reshape(36)
             out[36 * (n + j):36 * (n + j + 1)] = self.Imats[j].T.reshape(36)
         return out
+
+
+class SubForest:
+    """The joints first..first+count-1 of a robot as a robot of their own (local ids 0..count-1): a run of consecutive base-rooted
+    trees.  Base-rooted trees do not interact -- the joint-space inertia matrix, the bias forces and their gradients are block
+    diagonal over them -- so a group of trees can be evaluated on its own (emit/wave.py: one wavefront per group)."""
+
+    def __init__(self, spec, first, count):
+        ids = list(range(first, first + count))
+        for j in ids:
+            assert spec.parent[j] == -1 or first <= spec.parent[j] < first + count, "a sub-forest must be closed under parents"
+            assert all(first <= k < first + count for k in spec.subtree[j]), "a sub-forest must be closed under subtrees"
+        self.full = spec
+        self.first, self.n = first, count
+        self.name = "%s[%d:%d]" % (spec.name, first, first + count)
+        loc = lambda j: j - first
+        self.parent = [(-1 if spec.parent[j] == -1 else loc(spec.parent[j])) for j in ids]
+        self.S_ind = [spec.S_ind[j] for j in ids]
+        self.ancestors = [[loc(a) for a in spec.ancestors[j]] for j in ids]
+        self.subtree = [[loc(a) for a in spec.subtree[j]] for j in ids]
+        self.children = [[loc(c) for c in spec.children[j]] for j in ids]
+        self.damping = [spec.damping[j] for j in ids]
+        self.Imats = [spec.Imats[j] for j in ids]
+        self.Xbasis = [spec.Xbasis[j] for j in ids]
+        self.uses_trig = [spec.uses_trig[j] for j in ids]
+        self.uses_theta = [spec.uses_theta[j] for j in ids]
+
+
+def base_trees(spec):
+    """[(first joint, joint count)] of the base-rooted trees, in id order (DFS pre-order ids: each tree is a contiguous range)."""
+    return [(j, len(spec.subtree[j])) for j in range(spec.n) if spec.parent[j] == -1]

@@ -136,7 +136,7 @@ class Tracer:
         op = key[0]
         if op == "in":
             return 0                                  # inputs arrive in the storage type
-        if op in ("lnd", "lo", "hi"):
+        if op in ("lnd", "lo", "hi", "bc"):
             return self.ntype[key[1]]                 # same value, same type
         if op == "cvt":
             return key[2]                             # explicit conversion to C (0) or D (1)
@@ -426,6 +426,37 @@ class Tracer:
         """Force `val` to be computed before this point (work that should overlap with another wave's producer phase)."""
         self.out("anchor", val)
 
+    # --- wave-per-configuration kernels: the lanes of ONE wavefront share a configuration (emit/wave.py) ------------------------
+    def bcast(self, a, lane):
+        """The value lane `lane` (a generation-time constant) holds, in every lane: a wave-uniform value (v_readlane_b32)."""
+        if isinstance(a.ref, float):
+            return a
+        assert self.ntype[abs(a.ref)] == 0, "broadcasts are done in the compute type C"
+        sign = 1 if a.ref > 0 else -1
+        return V(self, sign * self._node(("bc", abs(a.ref), int(lane), None)))
+
+    def utab_put(self, slot, val):
+        """Park a WAVE-UNIFORM value in the wave's LDS table (one word per slot: every lane writes the same value)."""
+        self.out("utab:%d" % slot, val)
+
+    def utab_get(self, slot):
+        """Re-load a parked uniform value (LDS broadcast read): a fresh node per request, so its live range starts here."""
+        self._utab_serial = getattr(self, "_utab_serial", 0) + 1
+        return self.inp("in.utab_get(%d)/*%d*/" % (slot, self._utab_serial))
+
+    def m_put(self, row, val):
+        """Lane k publishes entry [row][k] of a matrix whose column k it owns (Minv) to the wave's LDS."""
+        self.out("mput:%d" % row, val)
+
+    def m_get(self, row, col):
+        """Entry [row][col] of the published matrix as a wave-uniform value (LDS broadcast read); fresh node per request."""
+        self._m_serial = getattr(self, "_m_serial", 0) + 1
+        return self.inp("in.m_get(%d,%d)/*%d*/" % (row, col, self._m_serial))
+
+    def wave_sync(self):
+        """Wave-local LDS ordering point (s_waitcnt lgkmcnt(0) + compiler fences): lanes read what OTHER lanes of the wave wrote."""
+        self.out("wsync", 0.0)
+
     def launder(self, a):
         """Same value, but opaque to the compiler from here on (an empty asm with the register as in/out operand): a later
         expression over the laundered value is NOT a common subexpression of the same expression over the original, so
@@ -457,7 +488,7 @@ class Tracer:
         op, a, b, c = self.nodes[k]
         if op == "in":
             return ()
-        if op in ("lo", "hi", "lnd", "cvt"):
+        if op in ("lo", "hi", "lnd", "cvt", "bc"):
             return (a,)
         if op.startswith("pk"):
             return tuple(abs(r) for pair in (a, b, c) if pair is not None for r in pair if not isinstance(r, float))
@@ -576,6 +607,8 @@ class Tracer:
                 count[0] -= 1       # a register half of a packed value: no instruction
             elif op == "cvt":
                 lines.append("%sconst %s t%d = (%s)t%d;" % (indent, ty, k, ty, a))
+            elif op == "bc":
+                lines.append("%sconst %s t%d = grid_lanes::bcast(t%d, %d);" % (indent, ty, k, a, b))
             elif op == "pkfma":
                 lines.append("%sconst C2 t%d = grid_pk_fma(%s, %s, %s);" % (indent, k, self._pair_opnd(a), self._pair_opnd(b), self._pair_opnd(c)))
             elif op == "pkmul":
@@ -674,7 +707,17 @@ class Tracer:
             hp = self.ntype[k]
             rnd = (lambda x: x) if (hp or not f32) else r32
             g = lambda r: get(r, hp)
-            if op == "in" and a.startswith("in.tab_get("):
+            if op == "in" and (a.startswith("in.utab_get(") or a.startswith("in.m_get(")):
+                # wave tables: the LATEST value written to the slot before this read (slots are rewritten); a matrix read takes
+                # the value of the lane that owns the column (the batch axis of this evaluation is the lane axis)
+                args = a[a.index("(") + 1:a.index(")")].split(",")
+                dst = ("utab:" if a.startswith("in.utab_get(") else "mput:") + args[0]
+                src = [r for (d, r), pos in zip(self.outputs, self.out_pos) if d == dst and pos <= k]
+                assert src, "wave table slot %s read before it was written" % dst
+                x = np.asarray(get(src[-1], 0 if isinstance(src[-1], float) else self.ntype[abs(src[-1])]), dtype=np.float64).reshape(-1)
+                pick = x[int(args[1]) if (dst.startswith("mput:") and x.size > 1) else 0]
+                val[k] = rnd(pick + np.zeros(1))
+            elif op == "in" and a.startswith("in.tab_get("):
                 slot = a[len("in.tab_get("):a.index(")")]
                 src = [r for (dst, r) in self.outputs if dst == "tab:" + slot]
                 assert len(src) == 1 and (isinstance(src[0], float) or abs(src[0]) < k), "table slot read before it was written"
@@ -699,6 +742,9 @@ class Tracer:
                 val[k] = (rnd(get(a[0]) + get(b[0])), rnd(get(a[1]) + get(b[1])))
             elif op == "lnd":
                 val[k] = val[a]
+            elif op == "bc":
+                x = np.asarray(val[a], dtype=np.float64).reshape(-1)
+                val[k] = x[b if x.size > 1 else 0] + np.zeros(1)
             elif op == "cvt":
                 val[k] = rnd(val[a])
             elif op == "lo":

@@ -52,7 +52,7 @@ def _hipcc():
 
 def _source_fingerprint(extra=""):
     h = hashlib.sha256()
-    for root in (os.path.join(PKG_DIR, "emit"), os.path.join(PKG_DIR, "helpers"), os.path.join(PKG_DIR, "algorithms")):
+    for root in (os.path.join(PKG_DIR, "emit"), os.path.join(PKG_DIR, "helpers"), os.path.join(PKG_DIR, "algorithms")):      # (every .py of the generator)
         for fn in sorted(os.listdir(root)):
             if fn.endswith(".py"):
                 with open(os.path.join(root, fn), "rb") as fh:
@@ -118,6 +118,26 @@ def kernel_dependency_hashes(header_text, kernel_names):
     # the explicit-instantiation macros at the end name every kernel: keep only the lines that are not per-kernel macros
     outside = "\n".join(l for l in outside.splitlines() if not l.startswith("#define GRID_KERNEL_INST_")
                         and not l.startswith("#define GRID_FOR_EACH_KERNEL_INST") and not l.startswith("#define GRID_NUM_KERNEL_INSTANCES"))
+    # the accessor / sink structs of the helper section (`struct grid_xyz {` ... `};` with the template and comment lines in front)
+    # are hashed only into the kernels that use them: a NEW sink or accessor leaves every other kernel's object valid
+    always, helper = [], {}
+    lines = outside.split("\n")
+    i = 0
+    while i < len(lines):
+        m = re.match(r"^    struct (grid_\w+) \{$", lines[i])
+        if not m:
+            always.append(lines[i])
+            i += 1
+            continue
+        head = []
+        while always and re.match(r"^    (template\b|//|/\*\*| \*)", always[-1]):
+            head.insert(0, always.pop())
+        j = i
+        while j < len(lines) and lines[j] != "    };":
+            j += 1
+        helper[m.group(1)] = "\n".join(head + lines[i:j + 1])
+        i = j + 1
+    always = "\n".join(always)
     region = blocks[first:last]
     by_name = {}
     for idx, (nm, t) in enumerate(region):
@@ -128,8 +148,14 @@ def kernel_dependency_hashes(header_text, kernel_names):
     for (nm, t) in region:
         found = set(w for w in ident.findall(t) if w in by_name and w != nm)
         refs.append(found)
+    helper_refs = {nm: set(w for w in ident.findall(t) if w in helper and w != nm) for nm, t in helper.items()}
+    always_uses = set(w for w in ident.findall(always) if w in helper)          # (helpers that free functions of the section mention)
+    whole = hashlib.sha256(header_text.encode()).hexdigest()
     out = {}
     for k in kernel_names:
+        if k not in by_name:
+            out[k] = whole            # a kernel whose block was not recognised depends on everything (never a stale object)
+            continue
         seen = set()
         stack = [k]
         while stack:
@@ -139,10 +165,21 @@ def kernel_dependency_hashes(header_text, kernel_names):
             seen.add(nm)
             for idx in by_name[nm]:
                 stack.extend(refs[idx])
-        h = hashlib.sha256(outside.encode())
+        h = hashlib.sha256(always.encode())
+        used = set(always_uses)
         for idx, (nm, t) in enumerate(region):
             if nm in seen or nm is None:
                 h.update(t.encode())
+                used.update(w for w in ident.findall(t) if w in helper)
+        stack = list(used)
+        used = set()
+        while stack:
+            nm = stack.pop()
+            if nm not in used:
+                used.add(nm)
+                stack.extend(helper_refs[nm])
+        for nm in sorted(used):
+            h.update(helper[nm].encode())
         out[k] = h.hexdigest()
     return out
 
@@ -456,6 +493,10 @@ CAPI_SIGNATURES = [
     ("grid_set_coop", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     ("grid_get_coop", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     ("grid_kernel_attributes_coop", ctypes.c_int, [ctypes.c_int, _c_int_p]),
+    ("grid_wave_available", ctypes.c_int, [ctypes.c_int]),
+    ("grid_set_wave", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
+    ("grid_get_wave", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
+    ("grid_kernel_attributes_wave", ctypes.c_int, [ctypes.c_int, _c_int_p]),
     ("grid_workspace_count", ctypes.c_int, [ctypes.c_int]),
     ("grid_set_pipeline", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     ("grid_time_device", ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_float,
@@ -501,11 +542,14 @@ class GridLibrary:
         k = self.lib.grid_splits(alg, out, 16)
         return [int(out[i]) for i in range(k)]
 
-    def kernel_attributes(self, alg, variant=0, split=0, coop=False):
+    def kernel_attributes(self, alg, variant=0, split=0, coop=False, wave=False):
         """Resources of the kernel for `alg`: variant 1 = the qdd / qdd+Minv input variant; split = S > 1: the S-way
-        column-split kernel (what grid_get_split says a call dispatches); coop: the tile-cooperative kernel."""
+        column-split kernel (what grid_get_split says a call dispatches); coop: the tile-cooperative kernel; wave: the
+        wave-per-configuration kernel."""
         out = (ctypes.c_int * 4)()
-        if coop:
+        if wave:
+            self.check(self.lib.grid_kernel_attributes_wave(alg, out), "grid_kernel_attributes_wave")
+        elif coop:
             self.check(self.lib.grid_kernel_attributes_coop(alg, out), "grid_kernel_attributes_coop")
         elif split > 1:
             self.check(self.lib.grid_kernel_attributes_split(alg, split, out), "grid_kernel_attributes_split")
@@ -677,6 +721,16 @@ class GridHandle:
 
     def coop_available(self, alg):
         return int(self.L.lib.grid_coop_available(alg)) == 1
+
+    def set_wave(self, alg, mode):
+        """Wave-per-configuration kernel (small batches): 0 = automatic (default), 1 = never, 2 = always."""
+        self.L.check(self.L.lib.grid_set_wave(self._h, alg, int(mode)), "grid_set_wave")
+
+    def get_wave(self, alg, K):
+        return int(self.L.lib.grid_get_wave(self._h, alg, int(K))) == 1
+
+    def wave_available(self, alg):
+        return int(self.L.lib.grid_wave_available(alg)) == 1
 
     def set_pipeline(self, alg, mode):
         """0 = automatic (single kernel), 1 = single kernel, 2 = two-pass (workspace) variant."""

@@ -54,3 +54,26 @@ void hh_inner_chain(const float *x, float *qdd_out, float *dc_du_out, int K, flo
 }
 }
 extern "C" void hh_sincos(const float *x, float *s, float *c, int K) { for (int k = 0; k < K; k++) G::grid_sincos(x[k], s + k, c + k); }
+// the spatial-algebra device library (public surface of the reference's header, helpers/_spatial_algebra_helpers.py:35-257):
+// out = [mxK(x) | mxK_scaled(x, alpha) | y + mxK_peq(x) | y + mxK_peq_scaled(x, alpha)] for K = 0..5 through the runtime-selected
+// mxX family (6 x 4 x 6 values), then fx(x) (36, column-major), fx_zeroed on zeros (36), fx_times_v(x, y) (6), y + fx_times_v_peq(x, y) (6),
+// dot_prod<6,1,1>(x, y) and dot_prod<3,2,1>(x, y) (2)
+extern "C" void hh_spatial(const float *x, const float *y, float alpha, float *out) {
+    float *o = out;
+    for (int k = 0; k < 6; k++) {
+        G::mxX<float>(o, x, k); o += 6;
+        G::mxX_scaled<float>(o, x, alpha, k); o += 6;
+        for (int i = 0; i < 6; i++) o[i] = y[i];
+        G::mxX_peq<float>(o, x, k); o += 6;
+        for (int i = 0; i < 6; i++) o[i] = y[i];
+        G::mxX_peq_scaled<float>(o, x, alpha, k); o += 6;
+    }
+    G::fx<float>(o, x); o += 36;
+    for (int i = 0; i < 36; i++) o[i] = 0.0f;
+    G::fx_zeroed<float>(o, x); o += 36;
+    G::fx_times_v<float>(o, x, y); o += 6;
+    for (int i = 0; i < 6; i++) o[i] = y[i];
+    G::fx_times_v_peq<float>(o, x, y); o += 6;
+    float xm[6]; for (int i = 0; i < 6; i++) xm[i] = x[i];
+    o[0] = G::dot_prod<float, 6, 1, 1>(x, y); o[1] = G::dot_prod<float, 3, 2, 1>(xm, y);
+}

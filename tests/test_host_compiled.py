@@ -94,3 +94,32 @@ def test_inline_sincos_accuracy(harness):
     s = np.zeros_like(x); c = np.zeros_like(x)
     lib.hh_sincos(_p(x), _p(s), _p(c), len(x))
     assert np.isnan(s).all() and np.isnan(c).all()
+
+
+def test_spatial_algebra_device_library(harness):
+    """mx0..5 (+ _peq, _scaled, _peq_scaled, through the runtime-selected mxX family), fx, fx_zeroed, fx_times_v(_peq), dot_prod --
+    the reference header's device library (helpers/_spatial_algebra_helpers.py:35-257) -- against the oracle's cross-product
+    matrices: mxK(x) = crm(x)[:, K], fx(x) = crf(x) = -crm(x)^T (column-major), fx_times_v(x, y) = crf(x) y."""
+    name, lib = harness
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-2, 2, 6).astype(np.float32); y = rng.uniform(-2, 2, 6).astype(np.float32)
+    alpha = np.float32(0.37)
+    out = np.zeros(6 * 4 * 6 + 36 + 36 + 6 + 6 + 2, dtype=np.float32)
+    lib.hh_spatial(_p(x), _p(y), ctypes.c_float(alpha), _p(out))
+    x64, y64 = x.astype(np.float64), y.astype(np.float64)
+    crm = np.stack([O.mxS(k, x64) for k in range(6)], axis=1)       # column K of crm(x) = x x e_K
+    crf = O.fx(x64)
+    np.testing.assert_allclose(crf, -crm.T, atol=0)                   # the two oracle functions agree with the identity crf = -crm^T
+    o = 0
+    for k in range(6):
+        col = crm[:, k]
+        for expect in (col, col * alpha, y64 + col, y64 + col * alpha):
+            np.testing.assert_allclose(out[o:o + 6], expect, rtol=1e-6, atol=1e-6)
+            o += 6
+    for _ in range(2):
+        np.testing.assert_allclose(out[o:o + 36].reshape(6, 6).T, crf, rtol=1e-6, atol=1e-6)       # column-major
+        o += 36
+    np.testing.assert_allclose(out[o:o + 6], crf @ y64, rtol=1e-5, atol=1e-5); o += 6
+    np.testing.assert_allclose(out[o:o + 6], y64 + crf @ y64, rtol=1e-5, atol=1e-5); o += 6
+    np.testing.assert_allclose(out[o], x64 @ y64, rtol=1e-5)
+    np.testing.assert_allclose(out[o + 1], x64[0] * y64[0] + x64[2] * y64[1] + x64[4] * y64[2], rtol=1e-5)

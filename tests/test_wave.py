@@ -1,0 +1,127 @@
+"""Wave-per-configuration forward-dynamics-gradient kernel (emit/wave.py): the lanes of ONE wavefront share a configuration
+(reference mapping: one block per configuration, helpers/_code_generation_helpers.py:41-55).
+
+CPU: the traced wave cores interpreted with numpy, the batch axis of the interpreter being the 64 LANES of one wave (broadcasts,
+the uniform LDS table and the published Minv are interpreted as what they are), against the oracle; generation-time structure.
+GPU (-m gpu): the kernel through the C ABI at K = 1, 7, 64, 200 against the oracle and against the lane-per-configuration kernel."""
+import numpy as np
+import pytest
+
+from conftest import make_inputs, relerr
+from gridcodegenerator_amd.emit import wave
+from gridcodegenerator_amd.emit.model import RobotSpec, SubForest, base_trees
+
+
+def interpret_wave_cores(spec, q, qd, u, gravity=9.81, dtype="float64"):
+    """df_du (n x 2n) of ONE configuration from the wave cores of every joint group."""
+    n = spec.n
+    out = np.zeros((n, 2 * n))
+    lanes = np.arange(wave.WAVE)
+    for (first, m) in wave.wave_groups(spec):
+        tr = wave.core_forward_dynamics_gradient_wave(SubForest(spec, first, m))
+        kcol = lanes % m
+        inputs = {"in.lane_q()": q[first + kcol], "in.lane_qd()": qd[first + kcol], "in.lane_u()": u[first + kcol],
+                  "gravity": np.full(wave.WAVE, gravity)}
+        for node in tr.nodes[1:]:
+            if node[0] != "in":
+                continue
+            expr = node[1]
+            call = expr.split("/*")[0]
+            if call.startswith("in.mask_k("):
+                inputs[expr] = (kcol == int(call[len("in.mask_k("):-1])).astype(float)
+            elif call.startswith("in.mask_dq("):
+                inputs[expr] = (lanes == int(call[len("in.mask_dq("):-1])).astype(float)
+            elif call.startswith("in.mask_dqd("):
+                inputs[expr] = (lanes == m + int(call[len("in.mask_dqd("):-1])).astype(float)
+        vals = tr.evaluate(inputs, dtype=dtype)
+        for (dst, _), val in zip(tr.outputs, vals):
+            if isinstance(dst, int):
+                val = np.asarray(val) + np.zeros(wave.WAVE)
+                for lane in range(2 * m):
+                    out[first + dst, first + (lane % m) + (n if lane >= m else 0)] = val[lane]
+    return out
+
+
+@pytest.mark.parametrize("name", ["iiwa7", "mixed5", "atlas30"])
+def test_wave_cores_match_the_oracle_on_the_cpu(name, robots, tables):
+    from oracle import rbd_oracle as O
+    spec = RobotSpec(robots(name))
+    n = spec.n
+    q, qd, u = (a[0].astype(np.float64) for a in make_inputs(n, 1, 31))
+    ref = O.fd_grad(tables(name), q[None], qd[None], u[None])[0]
+    got = interpret_wave_cores(spec, q, qd, u)
+    assert np.abs(got - ref).max() < 1e-10 * max(1.0, np.abs(ref).max())
+    got32 = interpret_wave_cores(spec, q, qd, u, dtype="float32")       # fp32 storage, fused multiply-add: what the kernel computes
+    assert np.abs(got32 - ref).max() < 2e-4 * np.abs(ref).max()
+
+
+def test_wave_groups_are_runs_of_base_trees(robots):
+    """Atlas-30: torso + arms + neck | both legs; a single chain: one group; every joint in exactly one group; lanes suffice."""
+    spec = RobotSpec(robots("atlas30"))
+    assert base_trees(spec) == [(0, 18), (18, 6), (24, 6)]
+    assert wave.wave_groups(spec) == [(0, 18), (18, 12)]
+    assert wave.wave_groups(RobotSpec(robots("iiwa7"))) == [(0, 7)]
+    for name in ("iiwa7", "mixed5", "atlas30"):
+        s = RobotSpec(robots(name))
+        groups = wave.wave_groups(s)
+        assert sorted(j for (f, m) in groups for j in range(f, f + m)) == list(range(s.n))
+        assert all(2 * m <= wave.WAVE for (_, m) in groups)
+        for (f, m) in groups:
+            sub = SubForest(s, f, m)
+            assert all(p == -1 or 0 <= p < m for p in sub.parent)
+
+
+def test_generated_header_has_the_wave_kernel(tmp_path, monkeypatch, robots):
+    from gridcodegenerator_amd.GRiDCodeGenerator import GRiDCodeGenerator
+    monkeypatch.chdir(tmp_path)
+    gen = GRiDCodeGenerator(robots("mixed5"), FILE_NAMESPACE="grid_w")
+    gen.gen_all_code()
+    code = gen.code_str
+    assert "void forward_dynamics_gradient_kernel_wave(" in code and "grid_lanes::bcast(" in code
+    assert "in.utab_put(" in code and "in.m_get(" in code and "const int FD_DU_WAVE_WAVES = 2;" in code
+    assert "const int FD_DU_WAVE_AUTO_MAX_K = 0;" in code                   # small robots: on request only
+    assert gen.wave_stats["groups"] == [(0, 4), (4, 1)]
+    assert any("forward_dynamics_gradient_kernel_wave" in k for k in gen.kernel_instances)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("robot", ["iiwa7", "mixed5", "atlas30"])
+def test_wave_kernel_on_gpu(robot, tables):
+    """Through the C ABI at K = 1, 7, 64, 200 (+ a strided launch with few blocks): against the oracle, against the
+    lane-per-configuration kernel, rows past the batch untouched; the automatic choice follows the generated header."""
+    import torch
+    from gridcodegenerator_amd import host
+    from test_gpu_parity import TOL, oracle_all, pack
+    host.build_library(robot, host.DEFAULT_PRECISION)
+    T = tables(robot)
+    with host.GridHandle(robot, device=0, precision=host.DEFAULT_PRECISION) as h:
+        assert h.wave_available(host.ALG_FD_DU)
+        n = h.n
+        assert h.get_wave(host.ALG_FD_DU, 64) == (n > 12)                # automatic for large robots at small batches only
+        assert not h.get_wave(host.ALG_FD_DU, 16384)
+        for K in (1, 7, 64, 200):
+            q, qd, u = make_inputs(n, K, 40 + K)
+            ref = oracle_all(T, q, qd, u)
+            d_in = torch.from_numpy(pack(q, qd, u)).cuda()
+            h.set_wave(host.ALG_FD_DU, 1); h.set_coop(host.ALG_FD_DU, 1); h.set_split(host.ALG_FD_DU, 1)
+            plain = torch.zeros((K, 2 * n * n), dtype=torch.float32, device="cuda")
+            h.forward_dynamics_gradient_device(plain.data_ptr(), d_in.data_ptr(), 3 * n, K)
+            h.synchronize()
+            h.set_wave(host.ALG_FD_DU, 2); h.set_coop(host.ALG_FD_DU, 0); h.set_split(host.ALG_FD_DU, 0)
+            assert h.get_wave(host.ALG_FD_DU, K) and not h.get_coop(host.ALG_FD_DU, K)
+            outs = []
+            for blocks in (0, 1, 3):
+                out = torch.full((K + 2, 2 * n * n), 4.25, dtype=torch.float32, device="cuda")
+                h.forward_dynamics_gradient_device(out.data_ptr(), d_in.data_ptr(), 3 * n, K, blocks=blocks)
+                h.synchronize()
+                o = out.cpu().numpy()
+                assert np.all(o[K:] == 4.25)
+                outs.append(o[:K])
+            assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+            err = relerr(outs[0], ref["df_du"])[0]
+            assert err < TOL[robot]["df_du"] * (4 if K < 64 else 1), (robot, K, err)
+            assert relerr(outs[0], plain.cpu().numpy().astype(np.float64))[0] < 2 * TOL[robot]["df_du"]
+            # structural zeros (columns and rows of different base-rooted trees) are written as exact zeros
+            zero = np.abs(ref["df_du"]).max(axis=0) == 0.0
+            assert np.all(outs[0][:, zero] == 0.0)
+        h.set_wave(host.ALG_FD_DU, 0)
