@@ -139,6 +139,31 @@ def committed_traffic(robot, K, kernel, sha):
     return e.get("bytes"), e.get("round")
 
 
+def launch_ranks(n_gpus, argv):
+    """Run `bench.py --gpus N ...` as N ranks (python -m torch.distributed.run, one rank per GPU) from a process that has not
+    initialised the GPU; returns the exit code.  Fewer than N devices: an error, unless GRID_BENCH_REHEARSAL=1 asks for the
+    rehearsal (every rank on device 0, gloo).  GRID_BENCH_DRY_RUN=1 prints the command instead of running it (tests)."""
+    import socket
+    import subprocess
+    import torch                                   # (device_count() does not initialise the GPU runtime)
+    have = torch.cuda.device_count()
+    rehearsal = os.environ.get("GRID_BENCH_REHEARSAL") == "1"
+    if have < n_gpus and not rehearsal:
+        print("bench.py: --gpus %d requested but %d GPU(s) are visible; refusing to report a %d-GPU number from fewer devices "
+              "(GRID_BENCH_REHEARSAL=1 runs the multi-rank path on device 0 instead)" % (n_gpus, have, n_gpus), file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    if os.environ.get("GRID_BENCH_DRY_RUN") == "1":
+        print(" ".join(cmd))
+        return 0
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)            # the ranks' stdout (rank 0's JSON line) and stderr pass through
+
+
 class Workload:
     """One robot / batch on this rank's GPU: device-resident inputs and outputs, one handle, the launch closure."""
 
@@ -266,6 +291,13 @@ def main():
     args = ap.parse_args()
 
     rank, local_rank, world = sharding.env_rank()
+    if args.gpus > 1 and world == 1:
+        # `--gpus N` without a launcher: this process becomes the launcher.  It has not touched the GPU yet (and never will): the N
+        # ranks are children started through torch.distributed.run, rank 0's JSON line is relayed, the exit code is theirs.  A
+        # request that cannot be honoured fails loudly -- it is never answered with an `n_gpus: 1` line.
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    if world > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     # CPU baseline first: its worker processes are forked before this process initialises the GPU runtime
     cpu_line = None
     if world == 1 and not args.no_cpu_baseline:
@@ -275,8 +307,6 @@ def main():
         cpu_line = cpu_baseline(args.robot, q0, qd0, u0, args.cpu_seconds, cores)
 
     import torch
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     # rehearsal on a box with fewer GPUs than ranks (GRID_BENCH_REHEARSAL=1): every rank uses device 0 and the barrier /

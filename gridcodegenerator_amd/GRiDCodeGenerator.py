@@ -10,8 +10,8 @@ one-block-per-configuration CUDA.
 Generation-time knobs that have no reference counterpart are keyword-only:
     precision        "fp32" | "mixed" | "fp64"  arithmetic of the kernels for T=float (I/O stays T).  "fp32": compute type
                                       C = float.  "mixed": C = float, but the Minv recursion and qdd = Minv (u - c) -- the parts
-                                      whose round-off cond(M) amplifies -- run in double.  "fp64" (C = double) is correct on the
-                                      host but NOT verified on the GPU: needs allow_unverified=True
+                                      whose round-off cond(M) amplifies -- run in double.  "fp64": C = double everywhere (verified on
+                                      the GPU as a regression variant, 4.7x the time of fp32 for Atlas-30: DESIGN.md section 4)
     trig             "fast" | "libm" | "f64"   inline float sincos (default), library sincosf, or double then rounded
                                       as the reference does (helpers/_topology_helpers.py:127-128)
     suggested_threads, max_threads    threads per block the LDS counts are sized for (multiple of 64) / __launch_bounds__
@@ -21,11 +21,11 @@ Generation-time knobs that have no reference counterpart are keyword-only:
     pipeline         "auto" | bool    also emit the two-pass (workspace) variants of the gradient kernels; auto: n > 12
     grad_schedule    "auto" | "fused" | "recompute"   body of the single-kernel gradient cores: demand-ordered fused trace, or
                      column-serial with per-column recomputation of v, a, f (large robots); auto: recompute for n > 12.
-                     "fused" with n > 12 miscomputed on the GPU: needs allow_unverified=True
+                     ("fused" with n > 12 spills kilobytes per lane; correct since the kernels are branch-free)
     grad_splits      "auto" | list    column-split variants of the two gradient kernels to emit (small-batch speed)
-    waves_per_simd                    __launch_bounds__ occupancy hint for the unsplit kernels (caps registers at 512/w);
-                                      > 1 with n > 12 reproduces the register-capped builds that faulted: needs allow_unverified=True
-    allow_unverified bool             accept the combinations above that are known-bad or unverified on the GPU (for debugging them)
+    waves_per_simd                    __launch_bounds__ occupancy hint for the unsplit kernels (caps registers at 512/w)
+    allow_unverified bool             accept what reintroduces lane-divergent control flow (trig="libm"/"f64", out_mode="direct"):
+                                      such kernels are unverified on the GPU
     experimental     dict             measured-and-rejected or test-only variants, NOT part of the supported surface
                                       (defaults in EXPERIMENTAL_DEFAULTS; each is described and its measurement quoted there)
 """

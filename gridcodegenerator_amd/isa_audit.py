@@ -17,10 +17,10 @@ EXEC_WRITE = re.compile(r"^\s*(s_\w+_saveexec_b64|s_(or|and|andn2|xor|mov|not|or
                         r"|s_(mov|or|and|andn2)_b32\s+exec_(lo|hi)\b|v_cmpx_)")
 
 
-def code_objects(path, arch="gfx950"):
-    """Yield temporary ELF files, one per device code object of `arch` inside a host object / shared library (its .hip_fatbin
-    section is a concatenation of clang offload bundles, one per translation unit)."""
-    tmp = tempfile.mkdtemp(prefix="grid_isa_")
+def code_objects(path, tmp, arch="gfx950"):
+    """Yield ELF files written into the directory `tmp` (the caller owns and removes it), one per device code object of `arch`
+    inside a host object / shared library (its .hip_fatbin section is a concatenation of clang offload bundles, one per
+    translation unit)."""
     fat = os.path.join(tmp, "fat.bin")
     subprocess.check_call([os.path.join(LLVM_BIN, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, path])
     with open(fat, "rb") as fh:
@@ -57,8 +57,10 @@ def short_name(mangled):
 def audit(path, arch="gfx950"):
     """-> {mangled kernel name: (instructions, instructions that write EXEC)} for every function in the code objects of `path`."""
     out = {}
-    for elf in code_objects(path, arch):
-        txt = subprocess.run([os.path.join(LLVM_BIN, "llvm-objdump"), "-d", elf], stdout=subprocess.PIPE, text=True, check=True).stdout
+    with tempfile.TemporaryDirectory(prefix="grid_isa_") as tmp:      # (removed on every exit path: the audit runs at every build)
+        listings = [subprocess.run([os.path.join(LLVM_BIN, "llvm-objdump"), "-d", elf], stdout=subprocess.PIPE, text=True, check=True).stdout
+                    for elf in code_objects(path, tmp, arch)]
+    for txt in listings:
         cur = None
         for line in txt.splitlines():
             m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)

@@ -73,3 +73,13 @@ def relerr(got, ref):
     mask = np.abs(ref) > 1e-6 * scale
     worst = (err[mask] / np.abs(ref[mask])).max() if mask.any() else 0.0
     return err.max() / scale, worst
+
+
+def elementwise_err(got, ref, floor=1e-3):
+    """Worst ELEMENT-WISE relative error over the entries whose reference is at least `floor` of the batch scale max|ref|: the
+    entries a consumer can tell from zero.  (Entries near a zero crossing carry the absolute round-off of the scale; their relative
+    error is unbounded by construction and is what relerr()[1] reports.)"""
+    got = np.asarray(got, dtype=np.float64); ref = np.asarray(ref, dtype=np.float64)
+    scale = max(np.abs(ref).max(), 1e-300)
+    mask = np.abs(ref) >= floor * scale
+    return float((np.abs(got - ref)[mask] / np.abs(ref[mask])).max()) if mask.any() else 0.0

@@ -4,7 +4,7 @@ import json
 import sys
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np
-from conftest import make_inputs, relerr
+from conftest import elementwise_err, make_inputs, relerr
 from gridcodegenerator_amd import host
 from gridcodegenerator_amd.robots import get_robot
 from oracle import rbd_oracle as O
@@ -27,16 +27,18 @@ for robot in robots:
         gflat = lambda M: np.concatenate([O.flat_colmajor(M[:, :, :n]), O.flat_colmajor(M[:, :, n:])], axis=1)
         qdd32 = parts["qdd"].astype(np.float32)
         Minv32 = O.flat_colmajor(np.triu(parts["Minv"])).astype(np.float32)
-        res = {
-            "c": relerr(h.inverse_dynamics(x), parts["c"]),
-            "Minv": relerr(h.direct_minv(x), O.flat_colmajor(np.triu(parts["Minv"]))),
-            "qdd": relerr(h.forward_dynamics(x), parts["qdd"]),
-            "dc_du": relerr(h.inverse_dynamics_gradient(x), gflat(O.rnea_grad(T, q64, qd64, None))),
-            "dc_du_qdd": relerr(h.inverse_dynamics_gradient(x, qdd=qdd32), gflat(O.rnea_grad(T, q64, qd64, qdd32.astype(np.float64)))),
-            "df_du": relerr(h.forward_dynamics_gradient(x), gflat(df)),
-            "df_du_qdd_minv": relerr(h.forward_dynamics_gradient(x, qdd=qdd32, Minv=Minv32), gflat(df)),
+        pairs = {
+            "c": (h.inverse_dynamics(x), parts["c"]),
+            "Minv": (h.direct_minv(x), O.flat_colmajor(np.triu(parts["Minv"]))),
+            "qdd": (h.forward_dynamics(x), parts["qdd"]),
+            "dc_du": (h.inverse_dynamics_gradient(x), gflat(O.rnea_grad(T, q64, qd64, None))),
+            "dc_du_qdd": (h.inverse_dynamics_gradient(x, qdd=qdd32), gflat(O.rnea_grad(T, q64, qd64, qdd32.astype(np.float64)))),
+            "df_du": (h.forward_dynamics_gradient(x), gflat(df)),
+            "df_du_qdd_minv": (h.forward_dynamics_gradient(x, qdd=qdd32, Minv=Minv32), gflat(df)),
         }
-        report["%s:%d" % (robot, K)] = {k: [float(v[0]), float(v[1])] for k, v in res.items()}
-        print("%-8s K=%-5d %s" % (robot, K, "  ".join("%s %.2e/%.1e" % (k, v[0], v[1]) for k, v in res.items())), flush=True)
+        # per output: norm-wise / worst element-wise over entries above 1e-3 of the scale / worst element-wise over entries above 1e-6
+        res = {k: relerr(g, r) + (elementwise_err(g, r, 1e-3),) for k, (g, r) in pairs.items()}
+        report["%s:%d" % (robot, K)] = {k: [float(v[0]), float(v[2]), float(v[1])] for k, v in res.items()}
+        print("%-8s K=%-5d %s" % (robot, K, "  ".join("%s %.2e/%.1e/%.1e" % (k, v[0], v[2], v[1]) for k, v in res.items())), flush=True)
     h.close()
-print(json.dumps({"precision": precision, "errors_normwise_elementwise": report}))
+print(json.dumps({"precision": precision, "errors_normwise_elementwise1e-3_elementwise1e-6": report}))

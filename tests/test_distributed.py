@@ -80,3 +80,32 @@ def test_two_rank_gloo_run(tmp_path, tables):
     full = O.fd_grad(tables("iiwa7"), q, qd, u)
     got = np.concatenate([np.load(tmp_path / "shard0.npy"), np.load(tmp_path / "shard1.npy")])
     assert np.array_equal(got, full)
+
+
+def _bench(args, **env):
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None); e.pop("RANK", None); e.pop("LOCAL_RANK", None)
+    e.update(env)
+    return subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, cwd=REPO, env=e, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, text=True, timeout=300)
+
+
+def test_bench_gpus_n_without_a_launcher_cannot_report_one_gpu():
+    """`bench.py --gpus N` run directly (no WORLD_SIZE) becomes the launcher of N ranks -- before anything touches the GPU -- or fails
+    loudly; it never prints an `n_gpus: 1` line for an N-GPU request.  No GPU is visible here, so: (a) the plain request is refused
+    with a non-zero exit code and no JSON line; (b) the rehearsal request builds the torch.distributed.run command of N ranks
+    (dry run: the command is printed, not executed)."""
+    run = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1"])
+    assert run.returncode != 0 and "--gpus 2 requested" in run.stderr
+    assert not [l for l in run.stdout.splitlines() if l.startswith("{")]
+    run = _bench(["--gpus", "4", "--steps", "3", "--warmup", "1"], GRID_BENCH_REHEARSAL="1", GRID_BENCH_DRY_RUN="1")
+    assert run.returncode == 0, run.stderr
+    cmd = run.stdout.split()
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert os.path.basename(cmd[cmd.index("--master-port") + 2]) == "bench.py"
+
+
+def test_bench_rejects_a_world_size_that_contradicts_gpus():
+    run = _bench(["--gpus", "2", "--steps", "3"], WORLD_SIZE="4", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    assert run.returncode != 0 and "does not match WORLD_SIZE" in (run.stderr + run.stdout)

@@ -19,13 +19,16 @@ for K in Ks:
     def t():
         h.time_device(alg, d_out.data_ptr(), d_in.data_ptr(), 3 * n, K, reps=reps)     # ramp
         return min(h.time_device(alg, d_out.data_ptr(), d_in.data_ptr(), 3 * n, K, reps=reps) for _ in range(3)) * 1e3
+    h.set_wave(alg, 1)
     h.set_coop(alg, 1); h.set_split(alg, 1); row.append("unsplit %8.2f us" % t())
     h.set_split(alg, 0); row.append("auto-split(S=%d) %8.2f us" % (h.get_split(alg, K), t()))
     if h.coop_available(alg):
         h.set_coop(alg, 2); us = t(); row.append("coop %8.2f us (%.3g evals/s)" % (us, K / us * 1e6))
         h.set_coop(alg, 0)
+    if h.wave_available(alg) and K <= 8192:
+        h.set_wave(alg, 2); us = t(); row.append("wave %8.2f us" % us); h.set_wave(alg, 0)
     print("%s %s K=%-8d | %s" % (robot, precision, K, " | ".join(row)), flush=True)
-for name, kw in (("unsplit", {}), ("coop", {"coop": True})):
+for name, kw in (("unsplit", {}), ("coop", {"coop": True}), ("wave", {"wave": True})):
     try:
         print(name, h.L.kernel_attributes(alg, **kw))
     except Exception as e:
