@@ -116,6 +116,8 @@ class AlgorithmEmitMixin:
                 return "GRID_KEEP(%s);" % val
             if dst.startswith("utab:"):
                 return "in.utab_put(%s, (T)(%s));" % (dst[5:], val)
+            if dst.startswith("utab2:"):
+                return "in.utab2_put(%s, (T)(%s));" % (dst[6:], val)
             if dst.startswith("mput:"):
                 return "in.m_put(%s, (T)(%s));" % (dst[5:], val)
             if dst == "wsync":
@@ -1428,8 +1430,8 @@ class AlgorithmEmitMixin:
         per_wave = 0
         layout = []
         for (first, m) in groups:
-            ut = 18 * m
-            utab_elems = 2 * ut + WAVE                 # table + the scratch words the lanes other than 0 write
+            ut = wave.WaveTable(m).count
+            utab_elems = 2 * ut + 2 * WAVE             # table + the scratch words the lanes other than 0 write (own lanes, a helper wave's lanes)
             mat_elems = 2 * 32 * m + WAVE              # published matrix (row stride 32) + scratch of the lanes >= m
             out_elems = WAVE * n                       # output image [64 columns][n rows]
             layout.append((ut, utab_elems, mat_elems, out_elems))
@@ -1444,12 +1446,29 @@ class AlgorithmEmitMixin:
                                % (self.wave_auto_max_k if n > 12 else 0))
         self.gen_add_code_line("const int FD_DU_WAVE_SHARED_MEM_COUNT = %d; // dynamic LDS of a block in T elements (%d per wave: uniform table, published Minv, output image)"
                                % (per_wave * W, per_wave))
+        roles = wave.wave_roles(self.spec, groups)                 # {helper wave: helped wave}
+        helped_by = {hd: hr for hr, hd in roles.items()}
+        self.wave_stats["roles"] = dict(roles)
         names = []
         for w, (first, m) in enumerate(groups):
+            # spatial inertias of the group's joints, entry-major [21][m]: lane l reads entry e of joint l mod m (in.lane_I)
+            upper = [(r, c) for r in range(6) for c in range(r, 6)]
+            vals = [repr(float(self.spec.Imats[first + k][r, c])) for (r, c) in upper for k in range(m)]
+            self.gen_add_code_line("static __device__ const float FD_DU_WAVE_INERTIA_W%d[%d] = {%s};" % (w, 21 * m, ", ".join(vals)))
+        for w, (first, m) in enumerate(groups):
             cname = "forward_dynamics_gradient_wave_core_w%d" % w
-            tr = wave.core_forward_dynamics_gradient_wave(SubForest(self.spec, first, m))
-            self._emit_core(cname, "Wave-per-configuration forward-dynamics gradient, joints %d..%d: lane l < %d is column l of d/dq, lane %d + l of d/dqd"
-                            % (first, first + m - 1, m, m), tr, order="creation")
+            kw = {}
+            role = ""
+            if w in roles:
+                f2, m2 = groups[roles[w]]
+                kw["helper_for"] = SubForest(self.spec, f2, m2)
+                role = "; first runs the first RNEA pass of wave %d's joints %d..%d (that wave is busy with its Minv recursion)" % (roles[w], f2, f2 + m2 - 1)
+            if w in helped_by:
+                kw["helped"] = True
+                role = "; its first RNEA pass is run by wave %d" % helped_by[w]
+            tr = wave.core_forward_dynamics_gradient_wave(SubForest(self.spec, first, m), barriers=bool(roles), **kw)
+            self._emit_core(cname, "Wave-per-configuration forward-dynamics gradient, joints %d..%d: lane l < %d is column l of d/dq, lane %d + l of d/dqd%s"
+                            % (first, first + m - 1, m, m, role), tr, order="creation")
             names.append(cname)
         self.kernel_instances.append("__global__ void @NS::forward_dynamics_gradient_kernel_wave<T>(T *, const T *, const int, "
                                      "const @NS::robotModel<T> *, const T, const int);")
@@ -1490,11 +1509,29 @@ class AlgorithmEmitMixin:
                 "for (int k = bid; k < NUM_TIMESTEPS; k += nblocks){", ], True)
             self.gen_add_code_lines([
                 "const T *row = d_q_qd_u + (size_t)k*stride_q_qd_u;",
-                "const grid_in_wave<T> in = {row[%d + kcol], row[%d + kcol], row[%d + kcol], s_utab, wput, s_mat, mput, lane, kcol, %d};"
-                % (first, n + first, 2 * n + first, m),
+                "grid_in_wave<T> in = {row[%d + kcol], row[%d + kcol], row[%d + kcol], wput, mput, lane, kcol, %d, FD_DU_WAVE_INERTIA_W%d,"
+                % (first, n + first, 2 * n + first, m, w),
+                "                      (unsigned)reinterpret_cast<unsigned long long>(s_utab), (unsigned)reinterpret_cast<unsigned long long>(s_mat)};",
+            ])
+            if w in roles:
+                hw = roles[w]
+                f2, m2 = groups[hw]
+                ut2 = layout[hw][0]
+                self.gen_add_code_lines([
+                    "{   // helper role: the first RNEA pass of wave %d's joints goes into THAT wave's table" % hw,
+                    "    T *s_utab2 = reinterpret_cast<T *>(s_grid_dyn) + %d*%d;" % (hw, per_wave),
+                    "    const int kcol2 = lane %% %d;" % m2,
+                    "    in.q2_ = row[%d + kcol2]; in.qd2_ = row[%d + kcol2]; in.kcol2_ = kcol2; in.m2_ = %d; in.inertia2_ = FD_DU_WAVE_INERTIA_W%d;" % (f2, n + f2, m2, hw),
+                    "    in.wput2_ = (lane == 0) ? s_utab2 : (s_utab2 + %d + %d + lane);     // (scratch words BEHIND the ones that wave's own lanes use)" % (ut2, WAVE),
+                    "    in.utab2_ = (unsigned)reinterpret_cast<unsigned long long>(s_utab2);",
+                    "}",
+                ])
+            self.gen_add_code_lines([
                 "%s<T,C>(in, out, gravity);" % names[w],
                 "out.flush(d_df_du + (size_t)k*%d);" % (2 * n * n),
             ])
+            if roles:
+                self.gen_add_code_line("grid_block_sync();     // the tables are rewritten for the next configuration")
             self.gen_add_end_control_flow()
             self.gen_add_code_line("break;")
             self.gen_add_end_control_flow()

@@ -713,10 +713,30 @@ class Tracer:
                 args = a[a.index("(") + 1:a.index(")")].split(",")
                 dst = ("utab:" if a.startswith("in.utab_get(") else "mput:") + args[0]
                 src = [r for (d, r), pos in zip(self.outputs, self.out_pos) if d == dst and pos <= k]
+                if not src and dst.startswith("utab:") and "__utab_init__" in inputs:
+                    val[k] = rnd(np.float64(inputs["__utab_init__"][int(args[0])]) + np.zeros(1))       # (written by another wave's trace)
+                    continue
                 assert src, "wave table slot %s read before it was written" % dst
                 x = np.asarray(get(src[-1], 0 if isinstance(src[-1], float) else self.ntype[abs(src[-1])]), dtype=np.float64).reshape(-1)
                 pick = x[int(args[1]) if (dst.startswith("mput:") and x.size > 1) else 0]
                 val[k] = rnd(pick + np.zeros(1))
+            elif op == "in" and (a.startswith("in.lane_tab(") or a.startswith("in.lane_tab2(")):
+                # per-lane read of a wave's uniform table: word base + 6 * (the lane's joint) + r (inputs["__kcol__"]: joint per lane;
+                # the helper role reads the OTHER wave's table: suffix 2, inputs["__kcol2__"]); slots this trace never wrote come from
+                # inputs["__utab_init__"] (what another wave's trace wrote)
+                sfx = "2" if a.startswith("in.lane_tab2(") else ""
+                base, r = (int(x) for x in a[a.index("(") + 1:a.index(")")].split(","))
+                kcol = np.asarray(inputs["__kcol%s__" % sfx], dtype=int)
+                res = np.zeros(kcol.shape)
+                for jj in np.unique(kcol):
+                    slot = base + 6 * int(jj) + r
+                    src = [rr for (d, rr), pos in zip(self.outputs, self.out_pos) if d == "utab%s:%d" % (sfx, slot) and pos <= k]
+                    if src:
+                        x = np.asarray(get(src[-1], 0 if isinstance(src[-1], float) else self.ntype[abs(src[-1])]), dtype=np.float64).reshape(-1)
+                        res[kcol == jj] = x[0]
+                    else:
+                        res[kcol == jj] = inputs["__utab_init__"][slot]
+                val[k] = rnd(res)
             elif op == "in" and a.startswith("in.tab_get("):
                 slot = a[len("in.tab_get("):a.index(")")]
                 src = [r for (dst, r) in self.outputs if dst == "tab:" + slot]

@@ -52,17 +52,144 @@ def wave_groups(spec, max_waves=4):
     return groups
 
 
+def wave_roles(spec, groups):
+    """Which wave runs the first RNEA pass of another wave's group: {helper wave: helped wave} (at most one pair).  The wave of the
+    largest group is the block's critical path; its first RNEA pass (about a sixth of its instructions) needs nothing from the
+    articulated-inertia / Minv recursions that the same wave runs first, so the wave of the smallest group takes it over when that
+    still leaves it the shorter of the two (joint counts as the measure: work grows faster than linearly in them)."""
+    if len(groups) < 2:
+        return {}
+    big = max(range(len(groups)), key=lambda i: groups[i][1])
+    small = min(range(len(groups)), key=lambda i: groups[i][1])
+    if big == small or groups[small][1] * 1.25 > groups[big][1]:
+        return {}
+    return {small: big}
+
+
 class WaveTable:
     """Slots of the wave's uniform LDS table."""
 
     def __init__(self, m):
-        self.V, self.XA, self.F = 0, 6 * m, 12 * m
-        self.count = 18 * m
+        self.V, self.XA, self.F, self.A, self.C = 0, 6 * m, 12 * m, 18 * m, 24 * m
+        self.count = 25 * m
 
 
-def core_forward_dynamics_gradient_wave(sub):
+class _Rnea:
+    """The two RNEA passes of a wave core for the joint group `sub`, reading the lane's inputs and writing the group's uniform table
+    through the accessor methods with suffix `sfx` ("" = the wave's own group; "2" = ANOTHER wave's group: the helper role).
+
+    The recursions v_j = X_j v_p + S qd_j, a_j = X_j a_p + ... are serial along the tree and wave-uniform.  The per-joint force
+    f_j = I_j a_j + v_j x* I_j v_j is NOT a recursion: every lane evaluates it for ITS OWN joint (lane l: joint l mod m), dense, with
+    per-lane inertia entries (in.lane_I) on v, a gathered from the table -- 90 instructions for all joints at once instead of 66
+    uniform ones per joint -- and the backward accumulation f_p += X_j^T f_j broadcasts lane j's result."""
+
+    def __init__(self, tr, sub, g, sfx=""):
+        self.tr, self.sub, self.m, self.g, self.sfx = tr, sub, sub.n, g, sfx
+        self.tab = WaveTable(sub.n)
+        self.ql, self.qdl = tr.inp("in.lane_q%s()" % sfx), tr.inp("in.lane_qd%s()" % sfx)
+        self.sl = tr.sin(self.ql) if any(sub.uses_trig) else None
+        self.cl = tr.cos(self.ql) if any(sub.uses_trig) else None
+        self.Isym = {}
+        e = 0
+        for r in range(6):
+            for c in range(r, 6):
+                self.Isym[(r, c)] = self.Isym[(c, r)] = tr.inp("in.lane_I%s(%d)" % (sfx, e))
+                e += 1
+        self.own = {}                     # per-lane values that live on: v, I v, v x* I v of the lane's own joint
+        self.serial = 0
+
+    def put(self, slot, val):
+        self.tr.out("utab%s:%d" % (self.sfx, slot), val)
+
+    def lane_tab(self, base, r):
+        self.serial += 1
+        return self.tr.inp("in.lane_tab%s(%d,%d)/*%d*/" % (self.sfx, base, r, self.serial))
+
+    def sym_mv(self, x):
+        return [self.tr.dot([(self.Isym[(r, c)], x[c]) for c in range(6)]) for r in range(6)]
+
+    def uniform_inputs(self):
+        """q, trig of every joint as wave-uniform values (fresh broadcasts: their live ranges start at the request)."""
+        tr, sub = self.tr, self.sub
+        q = [tr.bcast(self.ql, j) for j in range(self.m)]
+        trig = [(tr.bcast(self.sl, j), tr.bcast(self.cl, j)) if sub.uses_trig[j] else None for j in range(self.m)]
+        return q, trig
+
+    def X_of(self, j, q, trig):
+        return alg.build_X_joint(self.tr, self.sub, j, q[j], trig[j])
+
+    def own_refs(self):
+        return [x.ref for k in self.own for x in self.own[k] if not isinstance(x.ref, float)]
+
+    def own_from_table(self):
+        """v, I v, v x* I v of the lane's own joint from the v another wave parked (helped role)."""
+        vl = [self.lane_tab(self.tab.V, r) for r in range(6)]
+        Ivl = self.sym_mv(vl)
+        self.own.update(v=vl, Iv=Ivl, fxv=alg.fxv(self.tr, vl, Ivl))
+
+    def run(self, qdd, first):
+        """One pass; returns the bias forces c (uniform).  first: computes and parks v; else reads it.  Parks a (both passes), and in
+        the second pass X_j a_parent and the accumulated forces for the gradient walk."""
+        tr, sub, m, tab, g = self.tr, self.sub, self.m, self.tab, self.g
+        q, trig = self.uniform_inputs()
+        qd = [tr.bcast(self.qdl, j) for j in range(m)]
+        v, a = [None] * m, [None] * m
+        for j in range(m):
+            p, s = sub.parent[j], sub.S_ind[j]
+            Xj = self.X_of(j, q, trig)
+            if first:
+                if p == -1:
+                    vj = alg.zeros6(tr)
+                    vj[s] = qd[j]
+                else:
+                    vj = alg.matvec(tr, Xj, v[p])
+                    vj[s] = vj[s] + qd[j]
+                for r in range(6):
+                    self.put(tab.V + 6 * j + r, vj[r])
+            else:
+                vj = [tr.utab_get(tab.V + 6 * j + r) for r in range(6)] if p != -1 else None       # (a base joint's a does not need v)
+            v[j] = vj
+            xa = alg.matvec(tr, Xj, a[p]) if p != -1 else [Xj[r][5] * g for r in range(6)]
+            aj = list(xa)
+            if p != -1:
+                aj = alg.vadd(aj, alg.mxS(tr, s, vj, qd[j]))
+            if qdd is not None:
+                aj[s] = aj[s] + qdd[j]
+            a[j] = aj
+            for r in range(6):
+                self.put(tab.A + 6 * j + r, aj[r])
+                if not first:
+                    self.put(tab.XA + 6 * j + r, xa[r])
+        tr.wave_sync()
+        al = [self.lane_tab(tab.A, r) for r in range(6)]
+        if first:
+            self.own_from_table()
+        fl = alg.vadd(self.sym_mv(al), self.own["fxv"])
+        f = [None] * m
+        c = [None] * m
+        for j in range(m - 1, -1, -1):
+            p, s = sub.parent[j], sub.S_ind[j]
+            fj = [tr.bcast(fl[r], j) for r in range(6)]
+            if f[j] is not None:
+                fj = alg.vadd(fj, f[j])
+            c[j] = fj[s] + qd[j] * sub.damping[j]
+            if not first:
+                for r in range(6):
+                    self.put(tab.F + 6 * j + r, fj[r])
+            if p != -1:
+                f[p] = alg.mattvec_acc(tr, self.X_of(j, q, trig), fj, f[p] if f[p] is not None else alg.zeros6(tr))
+        return c
+
+
+def core_forward_dynamics_gradient_wave(sub, helped=False, helper_for=None, barriers=False):
     """Forward-dynamics gradient of ONE configuration on one wavefront, for the sub-forest `sub` (model.SubForest or a whole
-    RobotSpec).  Inputs: in.lane_q/qd/u() = q, qd, u of joint (lane mod m); masks in.mask_k(j) = [lane mod m == j],
+    RobotSpec).
+
+    Roles inside a block (wave_roles): a wave with slack can run the first RNEA pass of ANOTHER wave's group while that wave is busy
+    with the articulated-inertia and Minv recursions (which do not need it): helper_for = that group's SubForest -- the pass writes
+    v, a and the bias forces c into the other wave's table (accessor methods with suffix 2), then both meet at ONE block barrier;
+    helped = True: this wave skips its first pass and takes c from its table after the barrier.  barriers = True: a wave that is
+    neither still executes the block's barrier.  Inputs: in.lane_q/qd/u() = q, qd, u of joint (lane mod m); masks in.mask_k(j) = [lane mod m == j],
     in.mask_dq(j) = [lane == j], in.mask_dqd(j) = [lane == m + j].  Outputs put(r, value): row r of the lane's gradient column."""
     m = sub.n
     tr = Tracer()
@@ -73,20 +200,24 @@ def core_forward_dynamics_gradient_wave(sub):
         serial[0] += 1
         return tr.inp("%s/*%d*/" % (expr, serial[0]))
 
-    ql, qdl, ul = tr.inp("in.lane_q()"), tr.inp("in.lane_qd()"), tr.inp("in.lane_u()")
     g = tr.inp("gravity")
-    sl = tr.sin(ql) if any(sub.uses_trig) else None
-    cl = tr.cos(ql) if any(sub.uses_trig) else None
+    if helper_for is not None:
+        # helper role first: the other group's first RNEA pass into the other wave's table, its bias forces behind it
+        mk_h = tr.cse_mark()
+        other = _Rnea(tr, helper_for, g, "2")
+        c_other = other.run(None, True)
+        for j in range(helper_for.n):
+            other.put(other.tab.C + j, c_other[j])
+        tr.barrier()
+        tr.fence()
+        tr.cse_release(mk_h)
+    elif barriers and not helped:
+        tr.barrier()
+    rn = _Rnea(tr, sub, g)
+    ql, qdl, sl, cl = rn.ql, rn.qdl, rn.sl, rn.cl
+    ul = tr.inp("in.lane_u()")
     I = alg.build_I(tr, sub)
-
-    def uniform_inputs():
-        """q, qd, trig of every joint as wave-uniform values (fresh broadcasts: their live ranges start at the request)."""
-        q = [tr.bcast(ql, j) for j in range(m)]
-        trig = [(tr.bcast(sl, j), tr.bcast(cl, j)) if sub.uses_trig[j] else None for j in range(m)]
-        return q, trig
-
-    def X_of(j, q, trig):
-        return alg.build_X_joint(tr, sub, j, q[j], trig[j])
+    uniform_inputs, X_of, own = rn.uniform_inputs, rn.X_of, rn.own
 
     # ---- phase 1: articulated-inertia recursion (uniform) + the Minv recursions with lane = column k ------------------------------
     mark = tr.cse_mark()
@@ -146,61 +277,25 @@ def core_forward_dynamics_gradient_wave(sub):
     tr.cse_release(mark, keep=keep_m)
 
     # ---- phases 2 + 3: RNEA at qdd = 0 (bias forces c), qdd, RNEA at qdd; v, X a_parent and the accumulated f go to the table --------
-    def rnea_pass(qdd, first):
-        mk = tr.cse_mark()
-        q, trig = uniform_inputs()
-        qd = [tr.bcast(qdl, j) for j in range(m)]
-        a = [None] * m
-        f = [None] * m
-        for j in range(m):
-            p, s = sub.parent[j], sub.S_ind[j]
-            Xj = X_of(j, q, trig)
-            if first:
-                if p == -1:
-                    vj = alg.zeros6(tr)
-                    vj[s] = qd[j]
-                else:
-                    vj = alg.matvec(tr, Xj, [tr.utab_get(tab.V + 6 * p + r) for r in range(6)])
-                    vj[s] = vj[s] + qd[j]
-                for r in range(6):
-                    tr.utab_put(tab.V + 6 * j + r, vj[r])
-            else:
-                vj = [tr.utab_get(tab.V + 6 * j + r) for r in range(6)]
-            xa = alg.matvec(tr, Xj, a[p]) if p != -1 else [Xj[r][5] * g for r in range(6)]
-            aj = list(xa)
-            if p != -1:
-                aj = alg.vadd(aj, alg.mxS(tr, s, vj, qd[j]))
-            if qdd is not None:
-                aj[s] = aj[s] + qdd[j]
-            a[j] = aj
-            if not first:
-                for r in range(6):
-                    tr.utab_put(tab.XA + 6 * j + r, xa[r])
-            Iv = alg.matvec(tr, I[j], vj)
-            f[j] = alg.vadd(alg.matvec(tr, I[j], aj), alg.fxv(tr, vj, Iv))
-        c = [None] * m
-        for j in range(m - 1, -1, -1):
-            p, s = sub.parent[j], sub.S_ind[j]
-            c[j] = f[j][s] + qd[j] * sub.damping[j]
-            if not first:
-                for r in range(6):
-                    tr.utab_put(tab.F + 6 * j + r, f[j][r])
-            if p != -1:
-                f[p] = alg.mattvec_acc(tr, X_of(j, q, trig), f[j], f[p])
-        return c, mk
-
-    c, mk = rnea_pass(None, True)
+    if helped:
+        tr.barrier()                           # the helper wave has parked v and the bias forces c in this wave's table
+        tr.fence()
+        rn.own_from_table()
+        c = [tr.utab_get(tab.C + j) for j in range(m)]
+    else:
+        c = rn.run(None, True)
     with tr.mixed_region():
         umc = [tr.bcast(ul, j) - c[j] for j in range(m)]
         qdd_lane = tr.dot([(Mcol[j], umc[j]) for j in range(m)])             # lane k: qdd_k = sum_j Minv[j][k] (u_j - c_j)
     qdd_lane = tr.cast(qdd_lane, 0) if tr.mixed else qdd_lane
     tr.anchor(qdd_lane)
     tr.fence()
-    tr.cse_release(mark)                      # (Minv columns are in LDS, the bias forces are folded into qdd: nothing else survives)
+    tr.cse_release(mark, keep=rn.own_refs())  # (Minv columns are in LDS, the bias forces are folded into qdd: only the lane's own v, I v survive)
+    mk = tr.cse_mark()
     qdd = [tr.bcast(qdd_lane, j) for j in range(m)]
-    _, mk = rnea_pass(qdd, False)
+    rn.run(qdd, False)
     tr.fence()
-    tr.cse_release(mk)
+    tr.cse_release(mk, keep=rn.own_refs())
 
     # ---- phase 4: dRNEA, lane = column, ONE depth-first walk over all joints ------------------------------------------------------
     dc = [tr.zero()] * m
@@ -230,7 +325,7 @@ def core_forward_dynamics_gradient_wave(sub):
             da = alg.matvec_acc(tr, Xj, da_p, da)
         sq, sqd = alg.mxS(tr, s, xa), alg.mxS(tr, s, vj)
         da = [tr.fma(mqd, sqd[r], tr.fma(mq, sq[r], da[r])) for r in range(6)]
-        Iv = alg.matvec(tr, I[j], vj)
+        Iv = [tr.bcast(own["Iv"][r], j) for r in range(6)]          # I_j v_j was formed by the lane that owns joint j
         df = alg.matvec(tr, I[j], da)
         df = alg.vadd(df, alg.fxv(tr, vj, alg.matvec(tr, I[j], dv)))
         df = alg.vadd(df, alg.fxv(tr, dv, Iv))

@@ -12,16 +12,43 @@ from gridcodegenerator_amd.emit import wave
 from gridcodegenerator_amd.emit.model import RobotSpec, SubForest, base_trees
 
 
-def interpret_wave_cores(spec, q, qd, u, gravity=9.81, dtype="float64"):
-    """df_du (n x 2n) of ONE configuration from the wave cores of every joint group."""
+def _lane_inputs(spec, first, m, q, qd, u, gravity, sfx=""):
+    lanes = np.arange(wave.WAVE)
+    kcol = lanes % m
+    inputs = {"in.lane_q%s()" % sfx: q[first + kcol], "in.lane_qd%s()" % sfx: qd[first + kcol], "__kcol%s__" % sfx: kcol}
+    if not sfx:
+        inputs["in.lane_u()"] = u[first + kcol]
+        inputs["gravity"] = np.full(wave.WAVE, gravity)
+    upper = [(r, c) for r in range(6) for c in range(r, 6)]
+    for e, (r, c) in enumerate(upper):
+        inputs["in.lane_I%s(%d)" % (sfx, e)] = np.array([spec.Imats[first + k][r, c] for k in kcol])
+    return inputs
+
+
+def interpret_wave_cores(spec, q, qd, u, gravity=9.81, dtype="float64", use_roles=True):
+    """df_du (n x 2n) of ONE configuration from the wave cores of every joint group, the helper / helped roles included: the
+    helper's trace is interpreted first and what it wrote into the other wave's table is handed to that wave's trace."""
     n = spec.n
     out = np.zeros((n, 2 * n))
     lanes = np.arange(wave.WAVE)
-    for (first, m) in wave.wave_groups(spec):
-        tr = wave.core_forward_dynamics_gradient_wave(SubForest(spec, first, m))
+    groups = wave.wave_groups(spec)
+    roles = wave.wave_roles(spec, groups) if use_roles else {}
+    helped_by = {hd: hr for hr, hd in roles.items()}
+    table_init = {}
+    order = sorted(range(len(groups)), key=lambda w: 0 if w in roles else 1)          # helper waves first
+    for w in order:
+        first, m = groups[w]
+        kw = {}
+        inputs = _lane_inputs(spec, first, m, q, qd, u, gravity)
+        if w in roles:
+            f2, m2 = groups[roles[w]]
+            kw["helper_for"] = SubForest(spec, f2, m2)
+            inputs.update(_lane_inputs(spec, f2, m2, q, qd, u, gravity, "2"))
+        if w in helped_by:
+            kw["helped"] = True
+            inputs["__utab_init__"] = table_init[w]
+        tr = wave.core_forward_dynamics_gradient_wave(SubForest(spec, first, m), barriers=bool(roles), **kw)
         kcol = lanes % m
-        inputs = {"in.lane_q()": q[first + kcol], "in.lane_qd()": qd[first + kcol], "in.lane_u()": u[first + kcol],
-                  "gravity": np.full(wave.WAVE, gravity)}
         for node in tr.nodes[1:]:
             if node[0] != "in":
                 continue
@@ -34,11 +61,14 @@ def interpret_wave_cores(spec, q, qd, u, gravity=9.81, dtype="float64"):
             elif call.startswith("in.mask_dqd("):
                 inputs[expr] = (lanes == m + int(call[len("in.mask_dqd("):-1])).astype(float)
         vals = tr.evaluate(inputs, dtype=dtype)
+        assert sum(1 for (dst, _) in tr.outputs if dst == "barrier") == (1 if roles else 0)      # every wave of a block: the same count
         for (dst, _), val in zip(tr.outputs, vals):
             if isinstance(dst, int):
                 val = np.asarray(val) + np.zeros(wave.WAVE)
                 for lane in range(2 * m):
                     out[first + dst, first + (lane % m) + (n if lane >= m else 0)] = val[lane]
+            elif isinstance(dst, str) and dst.startswith("utab2:"):
+                table_init.setdefault(roles[w], {})[int(dst[6:])] = float(np.asarray(val).reshape(-1)[0])
     return out
 
 
@@ -53,6 +83,8 @@ def test_wave_cores_match_the_oracle_on_the_cpu(name, robots, tables):
     assert np.abs(got - ref).max() < 1e-10 * max(1.0, np.abs(ref).max())
     got32 = interpret_wave_cores(spec, q, qd, u, dtype="float32")       # fp32 storage, fused multiply-add: what the kernel computes
     assert np.abs(got32 - ref).max() < 2e-4 * np.abs(ref).max()
+    plain = interpret_wave_cores(spec, q, qd, u, use_roles=False)       # every wave on its own (no helper): the same numbers
+    assert np.abs(plain - ref).max() < 1e-10 * max(1.0, np.abs(ref).max())
 
 
 def test_wave_groups_are_runs_of_base_trees(robots):
@@ -61,6 +93,8 @@ def test_wave_groups_are_runs_of_base_trees(robots):
     assert base_trees(spec) == [(0, 18), (18, 6), (24, 6)]
     assert wave.wave_groups(spec) == [(0, 18), (18, 12)]
     assert wave.wave_groups(RobotSpec(robots("iiwa7"))) == [(0, 7)]
+    assert wave.wave_roles(spec, wave.wave_groups(spec)) == {1: 0}        # the legs' wave runs the torso group's first RNEA pass
+    assert wave.wave_roles(RobotSpec(robots("iiwa7")), [(0, 7)]) == {}
     for name in ("iiwa7", "mixed5", "atlas30"):
         s = RobotSpec(robots(name))
         groups = wave.wave_groups(s)
