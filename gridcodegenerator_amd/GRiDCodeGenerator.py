@@ -58,6 +58,9 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, SpatialAlgebraEmitMixin, Al
                                 # 4-way splits run one wave per SIMD at the batch sizes they serve; the cap costs them 2-6 spilled values
                                 # (9.94 vs 9.86 us at K = 16384) and lets a second stream's launch share the chip.  Capping the 7-way split
                                 # so that its waves PAIR UP on SIMDs loses: 14.8 vs 11.1 us (profiles/r03/two_waves_per_simd.md)
+        split_half_columns=True,  # ... and the sets may hold HALF columns (d/dq and d/dqd of a column in different groups) where that
+                                # lowers the heaviest group: iiwa-7 dFD x4 2937 -> 2771 operations, dID x4 1658 -> 1507
+        in_rows=False,          # inputs by per-lane 16-byte row loads instead of coalesced loads staged through LDS (grid_rows)
         coop_hoist=False,       # tile-cooperative cores of small robots: force everything that does not depend on qdd in front of
                                 # the first barrier (and let the producer go without columns): 12.9 vs 12.1 us at K=16384
     )
@@ -125,6 +128,8 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, SpatialAlgebraEmitMixin, Al
         self.dot_ways = int(exp["dot_ways"])
         self.split_cap = tuple(int(x) for x in exp["split_cap"])
         self.coop_hoist = bool(exp["coop_hoist"])
+        self.in_rows = bool(exp["in_rows"])
+        self.split_half_columns = bool(exp["split_half_columns"])
         self.wave_auto_max_k = 1024        # batch sizes up to which large robots use the wave-per-configuration kernel by themselves
         self.kernel_instances = []
         self.split_stats = {}

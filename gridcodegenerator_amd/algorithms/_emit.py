@@ -124,7 +124,10 @@ class AlgorithmEmitMixin:
                 return "GRID_SCHED_FENCE(); in.sync(); GRID_SCHED_FENCE();"
         return "out.put(%s, (T)(%s));%s" % (dst, val, fence_after_store())
 
-    def _emit_load(self, dst, src, total, stride, piece=MAX_IN_PIECE):
+    def _emit_load(self, dst, src, total, stride, piece=MAX_IN_PIECE, rows=False):
+        if self.in_rows or rows:
+            self.gen_add_code_line("grid_rows::load<T,%d>(%s, %s, %s, k0, it, NUM_TIMESTEPS);" % (total, dst, src, stride))
+            return
         off = 0
         while off < total:
             p = min(piece, total - off)
@@ -162,7 +165,7 @@ class AlgorithmEmitMixin:
                  "GRID_MAX_THREADS threads is accepted (the dynamic LDS must cover ceil(threads/64) wave regions)"]
         if parts:
             notes += ["COLUMN-SPLIT variant for small batches: %d column groups %s; the grid's whole wavefronts are numbered block-major and"
-                      % (len(parts), [list(c) for (_, c) in parts]),
+                      % (len(parts), [(list(c) if not isinstance(c, tuple) else "dq%s+dqd%s" % (list(c[0]), list(c[1]))) for (_, c) in parts]),
                       "wave gw computes group gw %% %d of tile gw / %d (grid_tile_iter): with %d waves per block a tile's groups share a CU."
                       % (len(parts), len(parts), len(parts)),
                       "Every group repeats the shared prefix (X(q), Minv, RNEA) -- the SIMDs it uses would otherwise idle.",
@@ -171,7 +174,8 @@ class AlgorithmEmitMixin:
         self.gen_add_code_line("template <typename T, typename C = typename grid_compute<T>::type>")
         # the 2-way split is the one used when the batch fills the chip: cap it at 256 registers so two waves share a SIMD
         # (2nd argument = waves per SIMD).  Finer splits only run when there are fewer waves than SIMDs: no cap, no spills.
-        occ = 2 if (parts and len(parts) in getattr(self, "split_cap", (2,)) and n <= 12) else self.waves_per_simd
+        # (the finer splits only in the fp32 arithmetic: the double regions of a mixed build would spill 60+ values under the cap)
+        occ = 2 if (parts and len(parts) in getattr(self, "split_cap", (2,)) and n <= 12 and (len(parts) == 2 or self.precision == "fp32")) else self.waves_per_simd
         self.gen_add_code_line("__global__ __launch_bounds__(GRID_MAX_THREADS%s)" % (", %d" % occ if occ > 1 else ""))
         self.gen_add_code_line(sig + " {", True)
         self.gen_add_code_lines([
@@ -184,7 +188,11 @@ class AlgorithmEmitMixin:
         piece = self.io_layout[alg]["in_piece"]
         table = self.io_layout[alg].get("table", 0) if not parts else 0
         self.gen_add_code_line("T s_%s[%d];" % (pname, pcount))
-        self._emit_load("s_" + pname, "d_" + pname, pcount, pstride, piece)
+        # the S >= 3 splits of small robots serve batches that leave one wave per SIMD: per-lane 16-byte row loads (grid_rows) save
+        # the LDS round trip of the staged path (iiwa-7 K = 16384: dFD 9.97 -> 9.75 us, dID 7.13 -> 6.73 us); kernels that run with
+        # many waves per CU keep the coalesced staged loads (K = 1 M: 215 vs 272 us)
+        rows = bool(parts) and len(parts) >= 3 and n <= 12
+        self._emit_load("s_" + pname, "d_" + pname, pcount, pstride, piece, rows=rows)
         for (ename, ecount) in extras:
             if ecount > MAX_IN_PIECE:
                 # large optional inputs (Minv of a 30-joint robot: 900 values) are read where they are used, straight from
@@ -215,6 +223,16 @@ class AlgorithmEmitMixin:
         else:
             self.gen_add_code_line("switch (it.part){", True)
             for pi, (pcore, cols) in enumerate(parts):
+                if isinstance(cols, tuple):         # ([d/dq columns], [d/dqd columns]): one flush per half
+                    lo_cols, hi_cols = cols
+                    assert not direct and 64 * n * max(len(lo_cols), len(hi_cols)) <= self.lds_per_wave(alg)
+                    self.gen_add_code_line("case %d: {" % pi, True)
+                    self.gen_add_code_line("grid_out_colset2<T,%d,%d,%d,%s> out = {s_wave, d_%s, k0, it.lane, it.W, NUM_TIMESTEPS};   // d/dq columns %s, d/dqd columns %s"
+                                           % (n_out, n, len(lo_cols), ",".join(str(c) for c in list(lo_cols) + list(hi_cols)), out_name, list(lo_cols), list(hi_cols)))
+                    self.gen_add_code_line("%s<T,C>(in, out, %s);" % (pcore, grav))
+                    self.gen_add_code_line("break;")
+                    self.gen_add_end_control_flow()
+                    continue
                 len0 = n * len(cols)
                 ch = chunk or self._chunk_for(len0)
                 assert 64 * ch <= self.lds_per_wave(alg)
@@ -223,9 +241,12 @@ class AlgorithmEmitMixin:
                 if not contiguous:
                     assert not direct and 64 * n <= self.lds_per_wave(alg)
                     # one flush per half when the whole set fits the wave's LDS region, else one per column
-                    sink = "grid_out_colset" if 64 * len0 <= self.lds_per_wave(alg) else "grid_out_cols"
-                    self.gen_add_code_line("%s<T,%d,%d,%s> out = {s_wave, d_%s, k0, it.lane, it.W, NUM_TIMESTEPS};   // columns %s"
-                                           % (sink, n_out, n, ",".join(str(c) for c in cols), out_name, list(cols)))
+                    if 64 * len0 <= self.lds_per_wave(alg):
+                        self.gen_add_code_line("grid_out_colset2<T,%d,%d,%d,%s> out = {s_wave, d_%s, k0, it.lane, it.W, NUM_TIMESTEPS};   // columns %s (both halves)"
+                                               % (n_out, n, len(cols), ",".join(str(c) for c in list(cols) + list(cols)), out_name, list(cols)))
+                    else:
+                        self.gen_add_code_line("grid_out_cols<T,%d,%d,%s> out = {s_wave, d_%s, k0, it.lane, it.W, NUM_TIMESTEPS};   // columns %s"
+                                               % (n_out, n, ",".join(str(c) for c in cols), out_name, list(cols)))
                 elif direct:
                     self.gen_add_code_line("grid_out_direct<T,%d,%d,%d> out = {d_row};" % (n * cols[0], len0, n * n + n * cols[0]))
                 else:
@@ -451,8 +472,13 @@ class AlgorithmEmitMixin:
                 est = max(cores._arith_ops(builder(c)) for c in parts)
             elif use_sets and S >= 3:
                 # arbitrary column sets (exhaustive, exact: cores.optimal_column_sets) for the splits that serve small batches;
-                # the 2-way split serves full-chip batches, where contiguous columns give 3-4x longer store runs
+                # the 2-way split serves full-chip batches, where contiguous columns give 3-4x longer store runs.  Better still:
+                # sets of HALF columns (the d/dq and d/dqd halves of a column share only the prefix) where that lowers the maximum
                 parts, est = cores.optimal_column_sets(self.spec, S, full)
+                if self.split_half_columns:
+                    hparts, hest = cores.optimal_half_column_sets(self.spec, S, full)
+                    if hest < 0.98 * est and all(64 * n * max(len(lo), len(hi)) <= self.lds_per_wave("FD_DU") for (lo, hi) in hparts):
+                        parts, est = hparts, hest
             else:
                 parts, est = cores.balanced_column_split(self.spec, S, cost)
                 if displace_first and n <= 8 and 3 <= S < n and self.out_mode == "staged" and not getattr(builder, "recompute", False):
@@ -488,15 +514,16 @@ class AlgorithmEmitMixin:
     def _emit_split_family(self, alg, kernel_base, core_base, doc, out_name, primary, has_gravity, accessor, builder, launch_args):
         """Cores + kernels + a launcher for the column-split variants of a gradient kernel."""
         base, chosen = self._choose_splits(builder, displace_first=(alg == "ID_DU"))
-        self.split_stats[alg] = dict(base_ops=base, splits={S: dict(parts=[list(c) for c in parts], worst_ops=worst)
+        self.split_stats[alg] = dict(base_ops=base, splits={S: dict(parts=[(list(c) if not isinstance(c, tuple) else [list(c[0]), list(c[1])])
+                                                                            for c in parts], worst_ops=worst)
                                                              for (S, parts, worst) in chosen})
         for (S, parts, worst) in chosen:
             named = []
             for pi, cols in enumerate(parts):
                 cname = "%s_s%dp%d" % (core_base, S, pi)
                 rec = getattr(builder, "recompute", False)
-                self._emit_core(cname, "%s: column group %d of %d (columns %s of d/dq and of d/dqd)"
-                                % (doc, pi, S, list(cols)), builder(cols), order="creation" if rec else None,
+                what = ("columns %s of d/dq and of d/dqd" % list(cols)) if not isinstance(cols, tuple) else ("columns %s of d/dq, %s of d/dqd" % (list(cols[0]), list(cols[1])))
+                self._emit_core(cname, "%s: column group %d of %d (%s)" % (doc, pi, S, what), builder(cols), order="creation" if rec else None,
                                 fence_stores=(self.split_fences or S < 3))
                 named.append((cname, cols))
             self._emit_kernel(alg, "%s_split%d" % (kernel_base, S), None, doc + " (column-split x%d)" % S, out_name,

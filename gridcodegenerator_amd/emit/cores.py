@@ -101,14 +101,15 @@ def _out_grad(tr, spec, G, cols=None):
                 tr.out(n * n + n * col + row, G[row][col].hi)
         return
     i = 0                                   # (cols need not be contiguous: the column-set sink maps every column back)
-    for half in ("lo", "hi"):
-        for col in cols:
+    lo_cols, hi_cols = cols if isinstance(cols, tuple) else (cols, cols)      # a tuple: different column sets for d/dq and d/dqd
+    for half, group in (("lo", lo_cols), ("hi", hi_cols)):
+        for col in group:
             for row in range(n):
                 tr.out(i, getattr(G[row][col], half))
                 i += 1
 
 
-def core_inverse_dynamics_gradient(spec, use_qdd, cols=None):
+def core_inverse_dynamics_gradient(spec, use_qdd, cols=None):      # cols: None | [columns] | ([d/dq columns], [d/dqd columns])
     tr, ins, g, X, I = _setup(spec, ["q", "qd"] + (["qdd"] if use_qdd else []))
     c, v, a, f = alg.rnea(tr, spec, X, I, ins["qd"], ins.get("qdd"), g)
     dc = alg.rnea_grad(tr, spec, X, I, ins["qd"], v, a, f, g)
@@ -130,7 +131,7 @@ def core_forward_dynamics_gradient(spec, use_qdd_minv, cols=None):
         qdd = alg.fd_finish(tr, spec, Minv, ins["u"], c)
     c, v, a, f = alg.rnea(tr, spec, X, I, ins["qd"], qdd, g)
     dc = alg.rnea_grad(tr, spec, X, I, ins["qd"], v, a, f, g)
-    out = alg.fd_grad_finish(tr, spec, Minv, dc, cols)
+    out = alg.fd_grad_finish(tr, spec, Minv, dc, sorted(set(cols[0]) | set(cols[1])) if isinstance(cols, tuple) else cols)
     _out_grad(tr, spec, out, cols)
     return tr
 
@@ -511,6 +512,82 @@ def optimal_column_sets(spec, S, full):
 
     rec(0, [])
     parts = sorted([[c for c in range(n) if m >> c & 1] for m in best[1]], key=lambda p: p[0])
+    return parts, best[0]
+
+
+def optimal_half_column_sets(spec, S, full, restarts=20):
+    """Partition of the 2n HALF columns -- (column, d/dq) and (column, d/dqd) are separate items: the two halves of a gradient column
+    share nothing but the prefix -- into S groups minimising the largest group's arithmetic (cost of a group = live arithmetic nodes
+    of `full` when only its outputs are kept, as in optimal_column_sets).  2n items are too many for the exhaustive search; this is
+    longest-processing-time placement followed by single moves and swaps out of the heaviest group, from `restarts` deterministic
+    perturbed orders.  iiwa-7 forward-dynamics gradient, S = 4: 2771 operations against 2937 for whole columns.
+    Returns (parts, worst) with parts = [(d/dq columns, d/dqd columns)] sorted by their first column."""
+    import random
+    n = spec.n
+    roots = {}
+    for (dst, ref) in full.outputs:
+        if not isinstance(dst, str) and not isinstance(ref, float):
+            i = int(dst)
+            roots.setdefault(((i % (n * n)) // n, i // (n * n)), []).append(abs(ref))
+    arith = ("fma", "mul", "add", "pkfma", "pkmul", "pkadd")
+    is_arith = [False] + [full.nodes[k][0] in arith for k in range(1, len(full.nodes))]
+    bits = {}
+    for item in [(c, h) for c in range(n) for h in (0, 1)]:
+        live, stack = set(), list(roots.get(item, []))
+        while stack:
+            k = stack.pop()
+            if k not in live:
+                live.add(k)
+                stack.extend(d for d in full._deps(k) if d not in live)
+        mask = 0
+        for k in live:
+            if is_arith[k]:
+                mask |= 1 << k
+        bits[item] = mask
+    memo = {}
+
+    def cost(group):
+        key = frozenset(group)
+        if key not in memo:
+            m = 0
+            for it in key:
+                m |= bits[it]
+            memo[key] = bin(m).count("1")
+        return memo[key]
+    items = sorted(bits)
+    best = None
+    for trial in range(restarts):
+        rng = random.Random(trial)
+        order = sorted(items, key=lambda it: -cost([it]) + rng.random() * (0 if trial == 0 else 300))
+        groups = [[] for _ in range(S)]
+        for it in order:
+            k = min(range(S), key=lambda k: (cost(groups[k] + [it]), k))
+            groups[k].append(it)
+        improved = True
+        while improved:
+            improved = False
+            cs = [cost(gp) for gp in groups]
+            w = max(range(S), key=lambda i: cs[i])
+            moves = []
+            for it in groups[w]:
+                for k in range(S):
+                    if k == w:
+                        continue
+                    moves.append((it, k, None))
+                    moves.extend((it, k, jt) for jt in groups[k])
+            for (it, k, jt) in moves:
+                ng = [list(gp) for gp in groups]
+                ng[w].remove(it); ng[k].append(it)
+                if jt is not None:
+                    ng[k].remove(jt); ng[w].append(jt)
+                if all(ng) and max(cost(gp) for gp in ng) < cs[w]:
+                    groups, improved = ng, True
+                    break
+        worst = max(cost(gp) for gp in groups)
+        if all(groups) and (best is None or worst < best[0]):
+            best = (worst, [sorted(gp) for gp in groups])
+    parts = [(sorted(c for (c, h) in gp if h == 0), sorted(c for (c, h) in gp if h == 1)) for gp in best[1]]
+    parts.sort(key=lambda p: min(p[0] + p[1]))
     return parts, best[0]
 
 

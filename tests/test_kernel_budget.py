@@ -31,10 +31,11 @@ def test_small_robot_kernels_do_not_touch_scratch():
     for precision in ("fp32", "mixed"):
         for k in _resources("iiwa7", precision):
             assert k["sgpr_spills"] <= 32, k     # (mixed: double constants live in SGPR pairs; SGPR spills go to VGPR lanes, not scratch)
-            if "split2" not in k["name"]:      # (the 2-way split is capped at 256 registers for two waves per SIMD: 1 / 51 spilled values)
+            capped = any(t in k["name"] for t in ("split2", "split3", "split4"))
+            if not capped:
                 assert k["scratch"] == 0, k
-            else:
-                assert k["scratch"] <= 256, k
+            else:      # the 2-, 3- and 4-way splits are compiled for <= 256 registers (two blocks per CU: a second stream's launch
+                assert k["scratch"] <= 256, k      # can share the chip): a handful of spilled values, 0.8 % at K = 16384
 
 
 def test_atlas_column_groups_are_spill_free_after_the_addressing_fix():

@@ -7,7 +7,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 from gridcodegenerator_amd import host, robots  # noqa: E402
 
-VARIANTS = {"iiwa7_sets": dict(experimental={"split_sets": True}), "iiwa7_sc": dict(experimental={"split_sets": True, "split_cap": (2, 3, 4)})}
+VARIANTS = {"iiwa7_cols": dict(experimental={"split_half_columns": False})}
 for name, kw in VARIANTS.items():
     if name not in robots.REGISTERED_ROBOTS:
         robots.register_robot(name, lambda: robots.get_robot("iiwa7"))
@@ -41,20 +41,18 @@ if __name__ == "__main__":
                             print("MISMATCH", name, alg, S, threads, np.isnan(got).sum(), np.abs(got - ref[alg]).max())
             h.close()
         print("bitwise check of every split / block shape done", flush=True)
-        for K in (4096, 8192, 12288, 16384):
+        for K in (64, 1024, 4096, 8192, 16384):
             for name in ["iiwa7"] + list(VARIANTS):
                 h = host.GridHandle(name, precision="fp32"); n = h.n
                 x = np.random.default_rng(0).uniform(-1, 1, (K, 3 * n)).astype(np.float32)
                 d_in = torch.from_numpy(x).cuda(); d_out = torch.empty((K, 2 * n * n), dtype=torch.float32, device='cuda')
                 row = []
                 for alg, nm in ((host.ALG_FD_DU, "dFD"), (host.ALG_ID_DU, "dID")):
-                    for S in (4,):
-                        if S not in h.L.splits(alg):
-                            continue
+                    for S in (0,):
                         h.set_split(alg, S)
-                        for threads, tag in ((0, "one block per tile"), (64, "single-wave blocks")):
-                            h.time_device(alg, d_out.data_ptr(), d_in.data_ptr(), 3 * n, K, threads=threads, reps=300)
-                            t = min(h.time_device(alg, d_out.data_ptr(), d_in.data_ptr(), 3 * n, K, threads=threads, reps=300) for _ in range(5)) * 1e3
-                            row.append("%s x%d %s %6.2f us" % (nm, S, tag, t))
+                        for threads, tag in ((0, "auto"),):
+                            h.time_device(alg, d_out.data_ptr(), d_in.data_ptr(), 3 * n, K, threads=threads, reps=(300 if K <= 65536 else 20))
+                            t = min(h.time_device(alg, d_out.data_ptr(), d_in.data_ptr(), 3 * n, K, threads=threads, reps=(300 if K <= 65536 else 20)) for _ in range(5)) * 1e3
+                            row.append("%s auto(S=%d) %7.2f us" % (nm, h.get_split(alg, K), t))
                 print("K=%-6d %-11s | %s" % (K, name, " | ".join(row)), flush=True)
                 h.close()

@@ -1,7 +1,7 @@
 // Diagnostic (GPU box): where does a wave of the headline kernel spend its time?  Re-runs the body of
 // forward_dynamics_gradient_kernel_split4 (iiwa-7, generated header) with s_memtime / s_memrealtime stamps around the input
 // staging and around the core (+ output flushes).  Stamps go to a buffer of their own; the outputs are not affected.
-//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -DGRID_HEADER='"<_build>/grid_iiwa7_fp32.hip.h"' tools/ubench/phase_stamps.hip -o phase_stamps
+// built by __graft_entry__.build_ubench() (which also writes phase_stamps_cases.inc from the generated header)
 #include GRID_HEADER
 #include <algorithm>
 #include <cstdio>
@@ -23,13 +23,9 @@ void stamped(T *d_df_du, const T *d_q_qd_u, const int stride_q_qd_u, const T gra
         GRID_KEEP(s_q_qd_u[0]); GRID_KEEP(s_q_qd_u[20]);
         c1 = __builtin_amdgcn_s_memtime(); r1 = __builtin_amdgcn_s_memrealtime();
         const grid_in_ptrs<T> in = {s_q_qd_u, s_q_qd_u + 7, s_q_qd_u + 14, nullptr, nullptr};
-        switch (it.part){
-            case 0: { grid_out_staged<T,98,28,14,0,14,49> out = {s_wave, d_df_du, k0, it.lane, it.W, NUM_TIMESTEPS}; forward_dynamics_gradient_core_s4p0<T,C>(in, out, gravity); break; }
-            case 1: { grid_out_staged<T,98,14,7,14,7,63> out = {s_wave, d_df_du, k0, it.lane, it.W, NUM_TIMESTEPS}; forward_dynamics_gradient_core_s4p1<T,C>(in, out, gravity); break; }
-            case 2: { grid_out_staged<T,98,14,7,21,7,70> out = {s_wave, d_df_du, k0, it.lane, it.W, NUM_TIMESTEPS}; forward_dynamics_gradient_core_s4p2<T,C>(in, out, gravity); break; }
-            case 3: { grid_out_staged<T,98,42,21,28,21,77> out = {s_wave, d_df_du, k0, it.lane, it.W, NUM_TIMESTEPS}; forward_dynamics_gradient_core_s4p3<T,C>(in, out, gravity); break; }
-            default: break;
-        }
+        // the `switch (it.part){...}` of forward_dynamics_gradient_kernel_split4, copied from the generated header by
+        // __graft_entry__.build_ubench() (column sets and their sinks are the generator's choice)
+#include "phase_stamps_cases.inc"
         c2 = __builtin_amdgcn_s_memtime(); r2 = __builtin_amdgcn_s_memrealtime();
     }
     if (it.lane == 0 && it.k0_first < NUM_TIMESTEPS){
@@ -40,29 +36,30 @@ void stamped(T *d_df_du, const T *d_q_qd_u, const int stride_q_qd_u, const T gra
 }
 
 int main() {
-    const int K = 16384, n = NUM_JOINTS, tiles = K/64, blocks = tiles*4;
+    const int K = 16384, n = NUM_JOINTS, tiles = K/64, blocks = tiles;       // one block of 4 waves per tile: its four column groups
     std::vector<float> x((size_t)K*3*n);
     for (size_t i = 0; i < x.size(); i++) x[i] = 0.37f*(float)((i*7) % 11) - 1.3f;
     float *d_in, *d_out; unsigned long long *d_st;
-    CHECK(hipMalloc(&d_in, x.size()*4)); CHECK(hipMalloc(&d_out, (size_t)K*2*n*n*4)); CHECK(hipMalloc(&d_st, (size_t)blocks*8*8));
+    CHECK(hipMalloc(&d_in, x.size()*4)); CHECK(hipMalloc(&d_out, (size_t)K*2*n*n*4)); CHECK(hipMalloc(&d_st, (size_t)blocks*4*8*8));
     CHECK(hipMemcpy(d_in, x.data(), x.size()*4, hipMemcpyHostToDevice));
-    const size_t lds = 3136*sizeof(float);
-    for (int r = 0; r < 2000; r++) hipLaunchKernelGGL(stamped, dim3(blocks), dim3(64), lds, 0, d_out, d_in, 3*n, 9.81f, K, d_st);   // clock ramp
+    const size_t lds = 4*3136*sizeof(float);
+    for (int r = 0; r < 2000; r++) hipLaunchKernelGGL(stamped, dim3(blocks), dim3(256), lds, 0, d_out, d_in, 3*n, 9.81f, K, d_st);   // clock ramp
     CHECK(hipDeviceSynchronize());
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
-    for (int r = 0; r < 200; r++) hipLaunchKernelGGL(stamped, dim3(blocks), dim3(64), lds, 0, d_out, d_in, 3*n, 9.81f, K, d_st);
+    for (int r = 0; r < 200; r++) hipLaunchKernelGGL(stamped, dim3(blocks), dim3(256), lds, 0, d_out, d_in, 3*n, 9.81f, K, d_st);
     hipEventRecord(e1); CHECK(hipEventSynchronize(e1));
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    std::vector<unsigned long long> st((size_t)blocks*8);
+    const int waves = blocks*4;
+    std::vector<unsigned long long> st((size_t)waves*8);
     CHECK(hipMemcpy(st.data(), d_st, st.size()*8, hipMemcpyDeviceToHost));
     printf("kernel (with stamps) %.2f us per launch\n", ms*1e3/200);
     unsigned long long rmin = ~0ull, rmax = 0;
-    for (int w = 0; w < blocks; w++) { rmin = std::min(rmin, st[(size_t)w*8+3]); rmax = std::max(rmax, st[(size_t)w*8+5]); }
+    for (int w = 0; w < waves; w++) { rmin = std::min(rmin, st[(size_t)w*8+3]); rmax = std::max(rmax, st[(size_t)w*8+5]); }
     printf("first wave start -> last wave end: %.2f us (s_memrealtime, 100 MHz)\n", (rmax - rmin)*0.01);
     for (int part = 0; part < 4; part++) {
         std::vector<double> load_c, core_c, load_ns, core_ns, start_ns;
-        for (int w = 0; w < blocks; w++) { const unsigned long long *s = &st[(size_t)w*8]; if ((int)s[6] != part) continue;
+        for (int w = 0; w < waves; w++) { const unsigned long long *s = &st[(size_t)w*8]; if ((int)s[6] != part) continue;
             load_c.push_back((double)(s[1]-s[0])); core_c.push_back((double)(s[2]-s[1])); load_ns.push_back((s[4]-s[3])*10.0); core_ns.push_back((s[5]-s[4])*10.0);
             start_ns.push_back((s[3]-rmin)*10.0); }
         auto med = [](std::vector<double> v){ std::sort(v.begin(), v.end()); return v[v.size()/2]; };
