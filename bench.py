@@ -112,6 +112,14 @@ def cpu_baseline(robot_name, q, qd, u, seconds, cores):
     except (OSError, StopIteration):
         pass
     usable, affinity, quota = host_cores()
+    # the same leg also yields the checker values for the parity figures of the line (first 256 configurations, float64)
+    from gridcodegenerator_amd.robots import get_robot
+    from oracle import rbd_oracle as O
+    ns = min(256, K)
+    T = O.RobotTables(get_robot(robot_name))
+    c_ref = O.rnea(T, q64[:ns], qd64[:ns])[0]
+    qdd_ref = O.forward_dynamics(T, q64[:ns], qd64[:ns], u64[:ns])
+    globals()["_PARITY_REF"] = dict(n=ns, c=c_ref, qdd=qdd_ref)
     return dict(value=evals / dt, unit="evals/s", cores=cores, kind="port", cpu=cpu,
                 host_cores_usable=usable, host_cores_affinity=affinity, cgroup_cpu_quota=quota,
                 sample="oracle.fd_grad (numpy float64, batch-vectorised) over the same %d-configuration batch cut into %d slices, "
@@ -251,6 +259,29 @@ class Workload:
                          "kernel_evals_per_s": K / (kern_ms * 1e-3)},
         }
 
+    def parity_sample(self, ref):
+        """Norm-wise and worst element-wise (entries >= 1e-3 of the scale) error of the torques c and accelerations qdd -- what
+        north_star's 1e-6 bar names -- of the first ref["n"] configurations of this batch against the float64 checker values from
+        the cpu_baseline leg (report both figures and say which bar is met)."""
+        host, torch, n = self.host, self.torch, self.n
+        ns = ref["n"]
+        out = {}
+        for (name, alg, width) in (("c", host.ALG_ID, n), ("qdd", host.ALG_FD, n)):
+            buf = torch.empty((ns, width), dtype=torch.float32, device="cuda")
+            if alg == host.ALG_ID:
+                self.h.inverse_dynamics_device(buf.data_ptr(), self.d_in.data_ptr(), 3 * n, ns, gravity=GRAVITY, stream=self.stream)
+            else:
+                self.h.forward_dynamics_device(buf.data_ptr(), self.d_in.data_ptr(), 3 * n, ns, gravity=GRAVITY, stream=self.stream)
+            torch.cuda.synchronize()
+            got = buf.cpu().numpy().astype(np.float64)
+            err = np.abs(got - ref[name])
+            scale = np.abs(ref[name]).max()
+            big = np.abs(ref[name]) >= 1e-3 * scale
+            out[name] = {"normwise": float(err.max() / scale), "elementwise_above_1e-3_of_scale": float((err[big] / np.abs(ref[name][big])).max())}
+        out["bar"] = "north_star 1e-6 relative is met NORM-WISE (max|err| / max|ref|); element-wise the entries above 1e-3 of the scale are within the second figure"
+        out["configurations"] = ns
+        return out
+
     def all_kernels(self):
         host, torch, n, K = self.host, self.torch, self.n, self.K
         kern = {}
@@ -325,6 +356,8 @@ def main():
     w = Workload(torch, host, args.robot, args.batch, args.precision, local_rank, 3 + rank, args.blocks, args.threads, args.split, args.coop)
     w.prewarm(args.prewarm_s)
     main_line = w.measure(sharding, dist, args.steps, args.warmup, world, reduce_device)
+    if rank == 0 and "_PARITY_REF" in globals():
+        main_line["config"]["parity_sample"] = w.parity_sample(globals()["_PARITY_REF"])
     kernels = w.all_kernels() if (args.all_kernels and rank == 0) else None
     w.close()
 

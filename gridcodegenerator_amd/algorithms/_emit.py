@@ -1374,7 +1374,8 @@ class AlgorithmEmitMixin:
         self.indent_level += 1
         self.gen_add_code_line("T s_q_qd_u[%d];" % (3 * n))
         self._emit_load("s_q_qd_u", "d_q_qd_u", 3 * n, "stride_q_qd_u", piece)
-        self.gen_add_code_line("const grid_in_coop<T> in = {s_q_qd_u, s_q_qd_u + %d, s_q_qd_u + %d, s_xch, it.lane};" % (n, 2 * n))
+        self.gen_add_code_line("const grid_in_coop<T> in = {s_q_qd_u, s_q_qd_u + %d, s_q_qd_u + %d, s_xch, it.lane, "
+                               "(unsigned)reinterpret_cast<unsigned long long>(s_xch) + (unsigned)sizeof(T)*it.lane};" % (n, 2 * n))
         self.gen_add_code_line("switch (it.wave_in_block){", True)
         for w, (cname, cols) in enumerate(names):
             if not cols:        # a producer without gradient columns: Minv and qdd only
