@@ -131,6 +131,12 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, SpatialAlgebraEmitMixin, Al
         self.in_rows = bool(exp["in_rows"])
         self.split_half_columns = bool(exp["split_half_columns"])
         self.wave_auto_max_k = 1024        # batch sizes up to which large robots use the wave-per-configuration kernel by themselves
+        # ... for the other algorithms, by robot size: measured on MI355X with tools/latency_all.py (profiles/r03/latency_all_*.txt), us per
+        # launch lane-per-configuration / wave-per-configuration.  Atlas-30: ID 9.9 / 6.6 at K = 1024 (9.9 / 13.9 at 2048), MINV 32.4 / 27.8
+        # at 2048 (33 / 53 at 4096), FD 28.7 / 19.6 at 1024 (28.8 / 37.8 at 2048), ID_DU 40.4 / 34.8 at 2048 (45 / 62 at 4096).  iiwa-7:
+        # ID 3.6 / 3.2 at 512, MINV 4.8 / 3.4 at 1024, FD 5.0 / 4.5 at 512, gradients slower at every K.  mixed-5: no gain.
+        self.wave_auto_other = ({"ID": 1024, "MINV": 2048, "FD": 1024, "ID_DU": 2048} if self.spec.n > 12 else
+                                {"ID": 512, "MINV": 1024, "FD": 512, "ID_DU": 0} if self.spec.n >= 7 else {"ID": 0, "MINV": 0, "FD": 0, "ID_DU": 0})
         self.kernel_instances = []
         self.split_stats = {}
         self.emit_inner_api = bool(emit_inner_api)
@@ -264,6 +270,7 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, SpatialAlgebraEmitMixin, Al
         self.gen_forward_dynamics_gradient_host()        # (after the cooperative kernel, which the wrappers dispatch for large robots)
         self.gen_forward_dynamics_gradient_rollout(use_thread_group)
         self.gen_forward_dynamics_gradient_wave(use_thread_group)       # (last: its kernel instance is appended, earlier kernels keep their object-cache keys)
+        self.gen_wave_kernels_other(use_thread_group)
         self.gen_init_close_grid()
         self.gen_add_end_control_flow()
         self.gen_kernel_instance_list()

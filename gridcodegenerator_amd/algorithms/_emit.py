@@ -1465,6 +1465,7 @@ class AlgorithmEmitMixin:
             layout.append((ut, utab_elems, mat_elems, out_elems))
             per_wave = max(per_wave, utab_elems + mat_elems + out_elems)
         self.wave_stats = dict(groups=list(groups), lds_bytes=4 * per_wave * W)
+        self.wave_layout, self.wave_per_wave_elems = layout, per_wave
         self.gen_add_code_line("const int FD_DU_WAVE_WAVES = %d; // wavefronts per block of the wave-per-configuration kernel: one block per configuration, "
                                "joint groups %s" % (W, [list(range(f, f + m)) for (f, m) in groups]))
         # batch sizes up to which the C ABI picks this kernel by itself: large robots while the batch leaves most of the chip idle
@@ -1593,6 +1594,135 @@ class AlgorithmEmitMixin:
         self.gen_add_code_line("__host__ inline")
         self.gen_add_code_line("bool forward_dynamics_gradient_wave_attributes(hipFuncAttributes *attr) {", True)
         self.gen_add_code_line("gpuErrchk(hipFuncGetAttributes(attr, reinterpret_cast<const void *>(&forward_dynamics_gradient_kernel_wave<T>))); return true;")
+        self.gen_add_end_function()
+
+    # the other four algorithms on the same wave-per-configuration phases (emit/wave.py: kind): the small-batch path of every kernel
+    WAVE_OTHERS = [
+        # alg, kind, kernel base, doc, output name, outputs per configuration (as a function of n), inputs
+        ("ID", "id", "inverse_dynamics", "Compute the RNEA (Recursive Newton-Euler Algorithm)", "c", lambda n: n, ("q_qd", True, False, True)),
+        ("MINV", "minv", "direct_minv", "Compute the inverse of the mass matrix", "Minv", lambda n: n * n, ("q", False, False, False)),
+        ("FD", "fd", "forward_dynamics", "Computes forward dynamics", "qdd", lambda n: n, ("q_qd_u", True, True, False)),
+        ("ID_DU", "id_du", "inverse_dynamics_gradient", "Computes the gradient of inverse dynamics", "dc_du", lambda n: 2 * n * n, ("q_qd", True, False, True)),
+    ]
+
+    def gen_wave_kernels_other(self, use_thread_group=False):
+        """`<algorithm>_kernel_wave` for RNEA, Minv, forward dynamics and the RNEA gradient: one block per configuration, one wavefront
+        per group of base-rooted trees, the phases of the forward-dynamics-gradient wave kernel that the algorithm needs.  The reference
+        runs all five algorithms block-per-configuration (its `_inner` family); these are their wave64 counterparts for batches that
+        leave the chip mostly idle."""
+        n = self.spec.n
+        groups = wave.wave_groups(self.spec) if self.precision != "fp64" else None
+        for (alg, kind, base, doc, out_name, n_out_f, (in_name, has_qd, has_u, has_qdd)) in self.WAVE_OTHERS:
+            launch_sig = ("bool %s_wave_launch(T *d_%s, const T *d_%s, const int stride_%s, %sconst robotModel<T> *d_robotModel, %sconst int num_timesteps, int blocks, hipStream_t stream)"
+                          % (base, out_name, in_name, in_name, "const T *d_qdd, " if has_qdd else "", "const T gravity, " if kind != "minv" else ""))
+            if not groups:
+                self.gen_add_code_line("const int %s_WAVE_AUTO_MAX_K = 0; // no wave-per-configuration kernel for this robot / arithmetic" % alg)
+                self.gen_add_code_lines(["template <typename T>", "__host__ inline", launch_sig.replace(" *d_%s" % out_name, " *").replace("T *d_", "T *") + " {return false;}", ""])
+                continue
+            W = len(groups)
+            per_wave = self.wave_per_wave_elems
+            n_out = n_out_f(n)
+            auto = self.wave_auto_other.get(alg, 0)
+            self.gen_add_code_line("const int %s_WAVE_AUTO_MAX_K = %d; // automatic choice of %s_kernel_wave up to this batch size (0: only on request)" % (alg, auto, base))
+            names = []
+            for w, (first, m) in enumerate(groups):
+                cname = "%s_wave_core_w%d" % (base, w)
+                tr = wave.core_forward_dynamics_gradient_wave(SubForest(self.spec, first, m), kind=kind)
+                self._emit_core(cname, "%s, wave-per-configuration, joints %d..%d" % (doc, first, first + m - 1), tr, order="creation")
+                names.append(cname)
+            grav = kind != "minv"
+            sig = "void %s_kernel_wave(T *d_%s, const T *d_%s, const int stride_%s, %sconst robotModel<T> *d_robotModel, %sconst int NUM_TIMESTEPS)" % (
+                base, out_name, in_name, in_name, "const T *d_qdd, " if has_qdd else "", "const T gravity, " if grav else "")
+            self.kernel_instances.append("__global__ void @NS::%s_kernel_wave<T>(%s);" % (
+                base, ", ".join(["T *", "const T *", "const int"] + (["const T *"] if has_qdd else []) + ["const @NS::robotModel<T> *"]
+                                + (["const T"] if grav else []) + ["const int"])))
+            self.gen_add_func_doc(doc + " (wave-per-configuration: the 64 lanes of a wavefront share ONE configuration)",
+                                  ["launch with EXACTLY %d threads per block and FD_DU_WAVE_SHARED_MEM_COUNT*sizeof(T) of dynamic LDS (use %s_wave_launch)" % (W * WAVE, base),
+                                   "block b computes configuration b, b + gridDim, ...; wave w of a block owns the joints %s" % [list(range(f, f + m)) for (f, m) in groups]]
+                                  + (["d_qdd may be nullptr (qdd = 0)"] if has_qdd else []),
+                                  ["d_%s is the output buffer, %d values per configuration" % (out_name, n_out),
+                                   "d_%s is the input buffer; stride_%s is the stride between configurations in it" % (in_name, in_name)], None)
+            self.gen_add_code_line("template <typename T, typename C = typename grid_compute<T>::type>")
+            self.gen_add_code_line("__global__ __launch_bounds__(%d)" % (W * WAVE))
+            self.gen_add_code_line(sig + " {", True)
+            self.gen_add_code_lines([
+                "extern __shared__ __align__(16) unsigned char s_grid_dyn[];",
+                "(void)d_robotModel;",
+                "const int tid = threadIdx.x + blockDim.x*(threadIdx.y + blockDim.y*threadIdx.z);",
+                "const int lane = tid & (GRID_WAVE_SIZE - 1);",
+                "const int wave = __builtin_amdgcn_readfirstlane(tid / GRID_WAVE_SIZE);",
+                "const int nblocks = gridDim.x*gridDim.y*gridDim.z;",
+                "const int bid = blockIdx.x + gridDim.x*(blockIdx.y + gridDim.y*blockIdx.z);",
+                "if (blockDim.x*blockDim.y*blockDim.z != %d){return;}    // (the launcher guarantees it)" % (W * WAVE),
+                "T *s_w = reinterpret_cast<T *>(s_grid_dyn) + wave*%d;" % per_wave,
+                "switch (wave){", ], True)
+            for w, (first, m) in enumerate(groups):
+                ut, utab_elems, mat_elems, out_elems = self.wave_layout[w]
+                self.gen_add_code_line("case %d: {" % w, True)
+                self.gen_add_code_lines([
+                    "const int kcol = lane %% %d;" % m,
+                    "T *s_utab = s_w; T *s_mat = s_w + %d; T *s_out = s_w + %d;" % (utab_elems, utab_elems + mat_elems),
+                    "T *wput = (lane == 0) ? s_utab : (s_utab + %d + lane);" % ut,
+                    "T *mput = (lane < %d) ? (s_mat + lane) : (s_mat + %d + lane);" % (m, 32 * m),
+                ])
+                if kind in ("minv", "id_du"):
+                    self.gen_add_code_line("grid_out_wave<T,%d,%d,%d,%d> out = {s_out, lane};" % (n, first, m, 1 if kind == "minv" else 2))
+                    self.gen_add_code_line("out.clear();")
+                else:
+                    self.gen_add_code_line("(void)s_out;")
+                self.gen_add_code_line("for (int k = bid; k < NUM_TIMESTEPS; k += nblocks){", True)
+                q_expr = "row[%d + kcol]" % first
+                qd_expr = ("row[%d + kcol]" % (n + first)) if has_qd else "static_cast<T>(0)"
+                u_expr = ("row[%d + kcol]" % (2 * n + first)) if has_u else "static_cast<T>(0)"
+                qdd_expr = ("(d_qdd != nullptr ? d_qdd[(size_t)k*%d + %d + kcol] : static_cast<T>(0))" % (n, first)) if has_qdd else "static_cast<T>(0)"
+                self.gen_add_code_lines([
+                    "const T *row = d_%s + (size_t)k*stride_%s;" % (in_name, in_name),
+                    "const grid_in_wave<T> in = {%s, %s, %s, wput, mput, lane, kcol, %d, FD_DU_WAVE_INERTIA_W%d," % (q_expr, qd_expr, u_expr, m, w),
+                    "                            (unsigned)reinterpret_cast<unsigned long long>(s_utab), (unsigned)reinterpret_cast<unsigned long long>(s_mat), %s};" % qdd_expr,
+                ])
+                g_expr = "gravity" if grav else "static_cast<T>(0)"
+                if kind == "id":
+                    self.gen_add_code_line("grid_out_wave_vec<T,%d> out = {d_%s + (size_t)k*%d};" % (first, out_name, n_out))
+                elif kind == "fd":
+                    self.gen_add_code_line("grid_out_wave_lane<T,%d> out = {d_%s + (size_t)k*%d, kcol};" % (first, out_name, n_out))
+                self.gen_add_code_line("%s<T,C>(in, out, %s);" % (names[w], g_expr))
+                if kind in ("minv", "id_du"):
+                    self.gen_add_code_line("out.flush(d_%s + (size_t)k*%d);" % (out_name, n_out))
+                self.gen_add_end_control_flow()
+                self.gen_add_code_line("break;")
+                self.gen_add_end_control_flow()
+            self.gen_add_code_line("default: break;")
+            self.gen_add_end_control_flow()
+            self.gen_add_end_function()
+            self.gen_add_func_doc("Launch %s_kernel_wave (asynchronous, on `stream`)" % base,
+                                  ["blocks <= 0: one block per configuration (capped at 8*SUGGESTED_MAX_BLOCKS; larger batches stride)",
+                                   "returns false when this robot has no such kernel"], [], None)
+            self.gen_add_code_line("template <typename T>")
+            self.gen_add_code_line("__host__ inline")
+            self.gen_add_code_line(launch_sig + " {", True)
+            args = ["d_" + out_name, "d_" + in_name, "stride_" + in_name] + (["d_qdd"] if has_qdd else []) + ["d_robotModel"] + (["gravity"] if grav else []) + ["num_timesteps"]
+            self.gen_add_code_lines([
+                "const size_t lds_bytes = (size_t)FD_DU_WAVE_SHARED_MEM_COUNT*sizeof(T);",
+                "if (lds_bytes > 65536){gpuErrchk(hipFuncSetAttribute(reinterpret_cast<const void *>(&%s_kernel_wave<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));}" % base,
+                "if (blocks <= 0 || blocks > num_timesteps){blocks = num_timesteps;}",
+                "if (blocks > 8*SUGGESTED_MAX_BLOCKS){blocks = 8*SUGGESTED_MAX_BLOCKS;}",
+                "%s_kernel_wave<T><<<dim3(blocks,1,1),dim3(%d,1,1),lds_bytes,stream>>>(%s);" % (base, W * WAVE, ",".join(args)),
+                "gpuErrchk(hipGetLastError());",
+                "return true;",
+            ])
+            self.gen_add_end_function()
+        self.gen_add_func_doc("hipFuncGetAttributes of the wave-per-configuration kernel of algorithm 0..3 (ID, MINV, FD, ID_DU)", ["returns false when this robot has none"], [], None)
+        self.gen_add_code_line("template <typename T>")
+        self.gen_add_code_line("__host__ inline")
+        self.gen_add_code_line("bool wave_attributes(int alg, hipFuncAttributes *attr) {", True)
+        if not groups:
+            self.gen_add_code_line("(void)alg; (void)attr; return false;")
+        else:
+            self.gen_add_code_line("const void *f = nullptr;")
+            for a, (_alg, _kind, base, *_rest) in enumerate(self.WAVE_OTHERS):
+                self.gen_add_code_line("if (alg == %d){f = reinterpret_cast<const void *>(&%s_kernel_wave<T>);}" % (a, base))
+            self.gen_add_code_line("if (f == nullptr){return false;}")
+            self.gen_add_code_line("gpuErrchk(hipFuncGetAttributes(attr, f)); return true;")
         self.gen_add_end_function()
 
     def _emit_no_coop(self):

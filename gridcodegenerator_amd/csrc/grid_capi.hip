@@ -252,16 +252,27 @@ static bool use_coop(const grid_handle *h, int alg, int K, const float *d_qdd, c
     return G::FD_DU_COOP_AUTO_MIN_TILES > 0 && tiles >= G::FD_DU_COOP_AUTO_MIN_TILES;     // (the generated header knows: see its comment)
 }
 
-// Wave-per-configuration kernel (forward-dynamics gradient): one block per configuration, the lanes of a wavefront are the gradient
-// columns of a group of base-rooted trees.  A configuration then takes as long as its longest group's chain ON 64 LANES, not as long as
-// the whole chain on one lane: the small-batch path.  Automatic up to FD_DU_WAVE_AUTO_MAX_K configurations (generated header: large
-// robots; the measurements are quoted there); an explicit choice of another variant wins.
-static bool wave_available(int alg) { return alg == GRID_ALG_FD_DU && G::FD_DU_WAVE_WAVES > 0; }
+// Wave-per-configuration kernels (all five algorithms): one block per configuration, the lanes of a wavefront are the gradient
+// columns / Minv columns / joints of a group of base-rooted trees.  A configuration then takes as long as its longest group's chain
+// ON 64 LANES, not as long as the whole chain on one lane: the small-batch path.  Automatic up to <ALG>_WAVE_AUTO_MAX_K configurations
+// (generated header: large robots; the measurements are quoted there); an explicit choice of another variant wins.
+static int wave_auto_max_k(int alg) {
+    switch (alg) {
+    case GRID_ALG_ID: return G::ID_WAVE_AUTO_MAX_K;
+    case GRID_ALG_MINV: return G::MINV_WAVE_AUTO_MAX_K;
+    case GRID_ALG_FD: return G::FD_WAVE_AUTO_MAX_K;
+    case GRID_ALG_ID_DU: return G::ID_DU_WAVE_AUTO_MAX_K;
+    case GRID_ALG_FD_DU: return G::FD_DU_WAVE_AUTO_MAX_K;
+    default: return 0;
+    }
+}
+static bool wave_available(int alg) { return alg >= 0 && alg <= 4 && G::FD_DU_WAVE_WAVES > 0; }
 static bool use_wave(const grid_handle *h, int alg, int K, const float *d_qdd, const float *d_Minv) {
-    if (!wave_available(alg) || d_qdd != nullptr || d_Minv != nullptr || h->wave[alg] == 1) return false;
+    if (!wave_available(alg) || d_Minv != nullptr || h->wave[alg] == 1) return false;
+    if (alg == GRID_ALG_FD_DU && d_qdd != nullptr) return false;       // (precomputed qdd/Minv: the lane-per-configuration kernel)
     if (h->wave[alg] == 2) return true;
     if (h->split[alg] != 0 || h->pipeline[alg] == 2 || h->coop[alg] == 2) return false;
-    return G::FD_DU_WAVE_AUTO_MAX_K > 0 && K <= G::FD_DU_WAVE_AUTO_MAX_K;
+    return wave_auto_max_k(alg) > 0 && K <= wave_auto_max_k(alg);
 }
 
 // Two-pass (workspace) variants: generated for robots whose gradient working set exceeds the register file.
@@ -291,7 +302,14 @@ static int launch_alg(grid_handle *h, int alg, float *d_out, const float *d_in, 
     dim3 b, t;
     launch_shape(K, blocks, threads, &b, &t);
     if (use_wave(h, alg, K, d_qdd, d_Minv)) {
-        G::forward_dynamics_gradient_wave_launch<T>(d_out, d_in, stride, h->d_robotModel, gravity, K, blocks > 0 ? blocks : 0, s);
+        const int nb = blocks > 0 ? blocks : 0;
+        switch (alg) {
+        case GRID_ALG_ID:    G::inverse_dynamics_wave_launch<T>(d_out, d_in, stride, d_qdd, h->d_robotModel, gravity, K, nb, s); break;
+        case GRID_ALG_MINV:  G::direct_minv_wave_launch<T>(d_out, d_in, stride, h->d_robotModel, K, nb, s); break;
+        case GRID_ALG_FD:    G::forward_dynamics_wave_launch<T>(d_out, d_in, stride, h->d_robotModel, gravity, K, nb, s); break;
+        case GRID_ALG_ID_DU: G::inverse_dynamics_gradient_wave_launch<T>(d_out, d_in, stride, d_qdd, h->d_robotModel, gravity, K, nb, s); break;
+        default:             G::forward_dynamics_gradient_wave_launch<T>(d_out, d_in, stride, h->d_robotModel, gravity, K, nb, s); break;
+        }
         return grid_check("kernel launch (wave-per-configuration)");
     }
     if (use_coop(h, alg, K, d_qdd, d_Minv)) {
@@ -468,7 +486,8 @@ int grid_get_wave(grid_handle *h, int alg, int num_timesteps) {
 int grid_kernel_attributes_wave(int alg, int *out) {
     if (out == nullptr || !wave_available(alg)) { g_last_error = "grid_kernel_attributes_wave: not available"; return -1; }
     hipFuncAttributes a;
-    G::forward_dynamics_gradient_wave_attributes<T>(&a);
+    if (alg == GRID_ALG_FD_DU) G::forward_dynamics_gradient_wave_attributes<T>(&a);
+    else G::wave_attributes<T>(alg, &a);
     if (int rc = grid_check("grid_kernel_attributes_wave")) return rc;
     out[0] = a.numRegs; out[1] = (int)a.sharedSizeBytes; out[2] = (int)a.localSizeBytes; out[3] = a.maxThreadsPerBlock;
     return 0;

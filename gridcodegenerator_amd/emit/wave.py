@@ -127,9 +127,10 @@ class _Rnea:
         Ivl = self.sym_mv(vl)
         self.own.update(v=vl, Iv=Ivl, fxv=alg.fxv(self.tr, vl, Ivl))
 
-    def run(self, qdd, first):
-        """One pass; returns the bias forces c (uniform).  first: computes and parks v; else reads it.  Parks a (both passes), and in
-        the second pass X_j a_parent and the accumulated forces for the gradient walk."""
+    def run(self, qdd, first, park_grad=None):
+        """One pass; returns the bias forces c (uniform).  first: computes and parks v; else reads it.  Parks a (every pass), and --
+        park_grad (default: not first) -- X_j a_parent and the accumulated forces for the gradient walk."""
+        park_grad = (not first) if park_grad is None else park_grad
         tr, sub, m, tab, g = self.tr, self.sub, self.m, self.tab, self.g
         q, trig = self.uniform_inputs()
         qd = [tr.bcast(self.qdl, j) for j in range(m)]
@@ -158,7 +159,7 @@ class _Rnea:
             a[j] = aj
             for r in range(6):
                 self.put(tab.A + 6 * j + r, aj[r])
-                if not first:
+                if park_grad:
                     self.put(tab.XA + 6 * j + r, xa[r])
         tr.wave_sync()
         al = [self.lane_tab(tab.A, r) for r in range(6)]
@@ -173,7 +174,7 @@ class _Rnea:
             if f[j] is not None:
                 fj = alg.vadd(fj, f[j])
             c[j] = fj[s] + qd[j] * sub.damping[j]
-            if not first:
+            if park_grad:
                 for r in range(6):
                     self.put(tab.F + 6 * j + r, fj[r])
             if p != -1:
@@ -181,9 +182,14 @@ class _Rnea:
         return c
 
 
-def core_forward_dynamics_gradient_wave(sub, helped=False, helper_for=None, barriers=False):
-    """Forward-dynamics gradient of ONE configuration on one wavefront, for the sub-forest `sub` (model.SubForest or a whole
-    RobotSpec).
+WAVE_KINDS = ("id", "minv", "fd", "id_du", "fd_du")
+
+
+def core_forward_dynamics_gradient_wave(sub, helped=False, helper_for=None, barriers=False, kind="fd_du"):
+    """Forward-dynamics gradient (kind "fd_du") of ONE configuration on one wavefront, for the sub-forest `sub` (model.SubForest or
+    a whole RobotSpec) -- or one of the other four algorithms from the same phases (the small-batch path of every kernel):
+    "id" RNEA bias forces c (qdd from in.lane_qdd(): zero when the caller has none), "minv" the upper triangle of Minv (lane k:
+    column k), "fd" qdd (lane k: qdd_k), "id_du" the RNEA gradient columns.
 
     Roles inside a block (wave_roles): a wave with slack can run the first RNEA pass of ANOTHER wave's group while that wave is busy
     with the articulated-inertia and Minv recursions (which do not need it): helper_for = that group's SubForest -- the pass writes
@@ -215,87 +221,110 @@ def core_forward_dynamics_gradient_wave(sub, helped=False, helper_for=None, barr
         tr.barrier()
     rn = _Rnea(tr, sub, g)
     ql, qdl, sl, cl = rn.ql, rn.qdl, rn.sl, rn.cl
-    ul = tr.inp("in.lane_u()")
+    ul = tr.inp("in.lane_u()") if kind in ("fd", "fd_du") else None
     I = alg.build_I(tr, sub)
     uniform_inputs, X_of, own = rn.uniform_inputs, rn.X_of, rn.own
 
     # ---- phase 1: articulated-inertia recursion (uniform) + the Minv recursions with lane = column k ------------------------------
+    need_minv = kind in ("minv", "fd", "fd_du")
     mark = tr.cse_mark()
-    q, trig = uniform_inputs()
-    X = [X_of(j, q, trig) for j in range(m)]
-    with tr.mixed_region():
-        IA = [[[I[j][r][c] for c in range(6)] for r in range(6)] for j in range(m)]
-        U, Dinv = [None] * m, [None] * m
-        Mcol = [None] * m                      # Mcol[j]: entry [j][k] of Minv in lane k
-        F = {}                                 # joint -> per-lane 6-vector: sum over the children c of X_c^T (F_c + U_c Minv[c][k])
-        for j in range(m - 1, -1, -1):
-            p, s = sub.parent[j], sub.S_ind[j]
-            Uj = [IA[j][r][s] for r in range(6)]
-            Dj = tr.rcp(Uj[s])
-            U[j], Dinv[j] = Uj, Dj
-            Mjk = Dj * fresh("in.mask_k(%d)" % j)                       # D_j in the lane that owns column j ...
-            if j in F:
-                Mjk = Mjk - Dj * F[j][s]                                # ... -D_j F_j[s] in the lanes of its subtree, 0 elsewhere
-            Mcol[j] = Mjk
-            if p == -1:
-                continue
-            Fjk = [Uj[r] * Mjk for r in range(6)]
-            if j in F:
-                Fjk = alg.vadd(F[j], Fjk)
-            F[p] = alg.mattvec_acc(tr, X[j], Fjk, F.get(p, alg.zeros6(tr)))
-            UD = [Uj[r] * Dj for r in range(6)]
-            Ia = [[None] * 6 for _ in range(6)]
-            for r in range(6):
-                for c in range(r, 6):
-                    val = tr.zero() if (r == s or c == s) else tr.fma(-UD[r], Uj[c], IA[j][r][c])
-                    Ia[r][c] = val
-                    Ia[c][r] = val
-            Tm = [[tr.dot([(Ia[r][k], X[j][k][c]) for k in range(6)]) for c in range(6)] for r in range(6)]
-            for r in range(6):
-                for c in range(r, 6):
-                    val = tr.dot([(X[j][k][r], Tm[k][c]) for k in range(6)], init=IA[p][r][c])
-                    IA[p][r][c] = val
-                    IA[p][c][r] = val
-        Fn = {}                                # forward pass: the acceleration of joint j caused by a unit torque at the lane's joint
-        for j in range(m):
-            p, s = sub.parent[j], sub.S_ind[j]
-            if p != -1 and p in Fn:
-                UX = alg.mattvec(tr, X[j], U[j])
-                Mcol[j] = Mcol[j] - Dinv[j] * tr.dot([(UX[r], Fn[p][r]) for r in range(6)])
-            if sub.children[j]:
-                Fj = alg.zeros6(tr)
-                Fj[s] = Mcol[j]
+    Mcol = None
+    if need_minv:
+        q, trig = uniform_inputs()
+        X = [X_of(j, q, trig) for j in range(m)]
+        with tr.mixed_region():
+            IA = [[[I[j][r][c] for c in range(6)] for r in range(6)] for j in range(m)]
+            U, Dinv = [None] * m, [None] * m
+            Mcol = [None] * m                      # Mcol[j]: entry [j][k] of Minv in lane k
+            F = {}                                 # joint -> per-lane 6-vector: sum over the children c of X_c^T (F_c + U_c Minv[c][k])
+            for j in range(m - 1, -1, -1):
+                p, s = sub.parent[j], sub.S_ind[j]
+                Uj = [IA[j][r][s] for r in range(6)]
+                Dj = tr.rcp(Uj[s])
+                U[j], Dinv[j] = Uj, Dj
+                Mjk = Dj * fresh("in.mask_k(%d)" % j)                       # D_j in the lane that owns column j ...
+                if j in F:
+                    Mjk = Mjk - Dj * F[j][s]                                # ... -D_j F_j[s] in the lanes of its subtree, 0 elsewhere
+                Mcol[j] = Mjk
+                if p == -1:
+                    continue
+                Fjk = [Uj[r] * Mjk for r in range(6)]
+                if j in F:
+                    Fjk = alg.vadd(F[j], Fjk)
+                F[p] = alg.mattvec_acc(tr, X[j], Fjk, F.get(p, alg.zeros6(tr)))
+                UD = [Uj[r] * Dj for r in range(6)]
+                Ia = [[None] * 6 for _ in range(6)]
+                for r in range(6):
+                    for c in range(r, 6):
+                        val = tr.zero() if (r == s or c == s) else tr.fma(-UD[r], Uj[c], IA[j][r][c])
+                        Ia[r][c] = val
+                        Ia[c][r] = val
+                Tm = [[tr.dot([(Ia[r][k], X[j][k][c]) for k in range(6)]) for c in range(6)] for r in range(6)]
+                for r in range(6):
+                    for c in range(r, 6):
+                        val = tr.dot([(X[j][k][r], Tm[k][c]) for k in range(6)], init=IA[p][r][c])
+                        IA[p][r][c] = val
+                        IA[p][c][r] = val
+            Fn = {}                                # forward pass: the acceleration of joint j caused by a unit torque at the lane's joint
+            for j in range(m):
+                p, s = sub.parent[j], sub.S_ind[j]
                 if p != -1 and p in Fn:
-                    Fj = alg.matvec_acc(tr, X[j], Fn[p], Fj)
-                Fn[j] = Fj
-    Mc = [tr.cast(e, 0) if tr.mixed else e for e in Mcol]
-    for j in range(m):
-        tr.m_put(j, Mc[j])
-    tr.wave_sync()
-    tr.fence()
-    keep_m = [e.ref for e in Mcol if not isinstance(e.ref, float)]
-    tr.cse_release(mark, keep=keep_m)
+                    UX = alg.mattvec(tr, X[j], U[j])
+                    Mcol[j] = Mcol[j] - Dinv[j] * tr.dot([(UX[r], Fn[p][r]) for r in range(6)])
+                if sub.children[j]:
+                    Fj = alg.zeros6(tr)
+                    Fj[s] = Mcol[j]
+                    if p != -1 and p in Fn:
+                        Fj = alg.matvec_acc(tr, X[j], Fn[p], Fj)
+                    Fn[j] = Fj
+        Mc = [tr.cast(e, 0) if tr.mixed else e for e in Mcol]
+        for j in range(m):
+            tr.m_put(j, Mc[j])
+        tr.wave_sync()
+        tr.fence()
+        keep_m = [e.ref for e in Mcol if not isinstance(e.ref, float)]
+        tr.cse_release(mark, keep=keep_m)
+
+    if kind == "minv":
+        for j in range(m):
+            tr.out(j, Mc[j] * fresh("in.mask_row_le(%d)" % j))        # the upper triangle: rows j <= the lane's column, zeros below
+        return tr
 
     # ---- phases 2 + 3: RNEA at qdd = 0 (bias forces c), qdd, RNEA at qdd; v, X a_parent and the accumulated f go to the table --------
-    if helped:
-        tr.barrier()                           # the helper wave has parked v and the bias forces c in this wave's table
+    if kind in ("id", "id_du"):
+        # inverse dynamics (and its gradient) at a GIVEN qdd: one pass; in.lane_qdd() is the lane's joint's qdd (zero when the caller
+        # passed none: the kernels of the reference that are "optimized for qdd = 0" are the same arithmetic with fewer terms)
+        qdd_in = tr.inp("in.lane_qdd()")
+        c = rn.run([tr.bcast(qdd_in, j) for j in range(m)], True, park_grad=(kind == "id_du"))
+        if kind == "id":
+            for j in range(m):
+                tr.out(j, c[j])
+            return tr
         tr.fence()
-        rn.own_from_table()
-        c = [tr.utab_get(tab.C + j) for j in range(m)]
+        tr.cse_release(mark, keep=rn.own_refs())
     else:
-        c = rn.run(None, True)
-    with tr.mixed_region():
-        umc = [tr.bcast(ul, j) - c[j] for j in range(m)]
-        qdd_lane = tr.dot([(Mcol[j], umc[j]) for j in range(m)])             # lane k: qdd_k = sum_j Minv[j][k] (u_j - c_j)
-    qdd_lane = tr.cast(qdd_lane, 0) if tr.mixed else qdd_lane
-    tr.anchor(qdd_lane)
-    tr.fence()
-    tr.cse_release(mark, keep=rn.own_refs())  # (Minv columns are in LDS, the bias forces are folded into qdd: only the lane's own v, I v survive)
-    mk = tr.cse_mark()
-    qdd = [tr.bcast(qdd_lane, j) for j in range(m)]
-    rn.run(qdd, False)
-    tr.fence()
-    tr.cse_release(mk, keep=rn.own_refs())
+        if helped:
+            tr.barrier()                           # the helper wave has parked v and the bias forces c in this wave's table
+            tr.fence()
+            rn.own_from_table()
+            c = [tr.utab_get(tab.C + j) for j in range(m)]
+        else:
+            c = rn.run(None, True)
+        with tr.mixed_region():
+            umc = [tr.bcast(ul, j) - c[j] for j in range(m)]
+            qdd_lane = tr.dot([(Mcol[j], umc[j]) for j in range(m)])             # lane k: qdd_k = sum_j Minv[j][k] (u_j - c_j)
+        qdd_lane = tr.cast(qdd_lane, 0) if tr.mixed else qdd_lane
+        if kind == "fd":
+            tr.out(0, qdd_lane)
+            return tr
+        tr.anchor(qdd_lane)
+        tr.fence()
+        tr.cse_release(mark, keep=rn.own_refs())  # (Minv columns are in LDS, the bias forces are folded into qdd: only the lane's own v, I v survive)
+        mk = tr.cse_mark()
+        qdd = [tr.bcast(qdd_lane, j) for j in range(m)]
+        rn.run(qdd, False)
+        tr.fence()
+        tr.cse_release(mk, keep=rn.own_refs())
 
     # ---- phase 4: dRNEA, lane = column, ONE depth-first walk over all joints ------------------------------------------------------
     dc = [tr.zero()] * m
@@ -351,6 +380,10 @@ def core_forward_dynamics_gradient_wave(sub, helped=False, helper_for=None, barr
     for root in [j for j in range(m) if sub.parent[j] == -1]:
         visit(root, None, None)
 
+    if kind == "id_du":
+        for r in range(m):
+            tr.out(r, dc[r])
+        return tr
     # ---- phase 5: df_du[:, col] = -Minv dc_du[:, col]; every Minv entry of the upper triangle read once (two multiply-adds) --------
     tr.fence()
     nz = alg.minv_zero_pattern(sub)

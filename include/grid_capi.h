@@ -116,15 +116,18 @@ int grid_set_coop(grid_handle *h, int alg, int mode);
 int grid_get_coop(grid_handle *h, int alg, int num_timesteps);
 int grid_kernel_attributes_coop(int alg, int *out);
 
-/* ---- wave-per-configuration forward-dynamics-gradient kernel: the small-batch path ----
+/* ---- wave-per-configuration kernels (all five algorithms): the small-batch path ----
  * The reference's own mapping -- one thread block per configuration whose threads split the 6x6 products and the gradient columns
  * (GRiDCodeGenerator.py:72-83 SUGGESTED_THREADS, helpers/_code_generation_helpers.py:41-55, algorithms/_inverse_dynamics_gradient.py:
  * 199-246,501-540) -- redone for 64-wide wavefronts: one block per configuration, one wavefront per group of base-rooted trees, lane =
- * gradient column (and Minv column); column-independent quantities are wave-uniform (v_readlane broadcasts), Minv crosses lanes
- * through wave-local LDS; no block barrier.  A batch of K <= #CUs configurations then costs one configuration's chain on 64 lanes
- * instead of the whole chain on one lane.  grid_wave_available: 1 if emitted for `alg` (GRID_ALG_FD_DU).  grid_set_wave: 0 =
- * automatic (default: batches up to FD_DU_WAVE_AUTO_MAX_K of the generated header -- large robots), 1 = never, 2 = always.
- * grid_get_wave: 1 if a call with `num_timesteps` would dispatch it (it takes precedence over the other variants). */
+ * gradient column / Minv column / joint; column-independent quantities are wave-uniform (v_readlane broadcasts), Minv crosses lanes
+ * through wave-local LDS.  A batch of K <= #CUs configurations then costs one configuration's chain on 64 lanes instead of the
+ * whole chain on one lane (Atlas-30, K = 64, us per launch, lanes -> waves: RNEA 9.6 -> 5.2, Minv 31 -> 7.6, FD 28 -> 10.1,
+ * RNEA gradient 37 -> 12.7, FD gradient 55 -> 19.9).  grid_wave_available: 1 if emitted for `alg` (every algorithm of a robot that
+ * has the kernels; none in all-double builds).  grid_set_wave: 0 = automatic (default: batches up to <ALG>_WAVE_AUTO_MAX_K of the
+ * generated header, which quotes the measurements behind each constant), 1 = never, 2 = always.  grid_get_wave: 1 if a call with
+ * `num_timesteps` would dispatch it (it takes precedence over the other variants).  The wave kernels take the optional d_qdd of
+ * RNEA and its gradient; a forward-dynamics-gradient call with precomputed d_qdd/d_Minv keeps to the lane-per-configuration kernel. */
 int grid_wave_available(int alg);
 int grid_set_wave(grid_handle *h, int alg, int mode);
 int grid_get_wave(grid_handle *h, int alg, int num_timesteps);

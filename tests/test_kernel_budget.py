@@ -62,7 +62,7 @@ def test_no_kernel_writes_exec(robot, precision):
         pytest.skip("library not built (run __graft_entry__.build())")
     res = isa_audit.audit(lib)
     assert len(res) >= 17
-    assert all(n > 500 for (n, _) in res.values()), "disassembly incomplete"
+    assert all(n > 300 for (n, _) in res.values()), "disassembly incomplete"       # (the smallest kernel: mixed5 direct_minv_kernel_wave, 445)
     assert {isa_audit.short_name(k): e for k, (n, e) in res.items() if e} == {}
 
 

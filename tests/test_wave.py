@@ -10,6 +10,7 @@ import pytest
 from conftest import make_inputs, relerr
 from gridcodegenerator_amd.emit import wave
 from gridcodegenerator_amd.emit.model import RobotSpec, SubForest, base_trees
+from gridcodegenerator_amd.robots import get_robot
 
 
 def _lane_inputs(spec, first, m, q, qd, u, gravity, sfx=""):
@@ -25,11 +26,13 @@ def _lane_inputs(spec, first, m, q, qd, u, gravity, sfx=""):
     return inputs
 
 
-def interpret_wave_cores(spec, q, qd, u, gravity=9.81, dtype="float64", use_roles=True):
+def interpret_wave_cores(spec, q, qd, u, gravity=9.81, dtype="float64", use_roles=True, kind="fd_du", qdd=None):
     """df_du (n x 2n) of ONE configuration from the wave cores of every joint group, the helper / helped roles included: the
-    helper's trace is interpreted first and what it wrote into the other wave's table is handed to that wave's trace."""
+    helper's trace is interpreted first and what it wrote into the other wave's table is handed to that wave's trace.  Other kinds:
+    "id" -> c (n), "minv" -> upper-triangular Minv (n x n), "fd" -> qdd (n), "id_du" -> dc_du (n x 2n)."""
     n = spec.n
-    out = np.zeros((n, 2 * n))
+    out = np.zeros({"id": (n,), "fd": (n,), "minv": (n, n)}.get(kind, (n, 2 * n)))
+    use_roles = use_roles and kind == "fd_du"
     lanes = np.arange(wave.WAVE)
     groups = wave.wave_groups(spec)
     roles = wave.wave_roles(spec, groups) if use_roles else {}
@@ -47,8 +50,9 @@ def interpret_wave_cores(spec, q, qd, u, gravity=9.81, dtype="float64", use_role
         if w in helped_by:
             kw["helped"] = True
             inputs["__utab_init__"] = table_init[w]
-        tr = wave.core_forward_dynamics_gradient_wave(SubForest(spec, first, m), barriers=bool(roles), **kw)
+        tr = wave.core_forward_dynamics_gradient_wave(SubForest(spec, first, m), barriers=bool(roles), kind=kind, **kw)
         kcol = lanes % m
+        inputs["in.lane_qdd()"] = (qdd[first + kcol] if qdd is not None else np.zeros(wave.WAVE))
         for node in tr.nodes[1:]:
             if node[0] != "in":
                 continue
@@ -60,13 +64,22 @@ def interpret_wave_cores(spec, q, qd, u, gravity=9.81, dtype="float64", use_role
                 inputs[expr] = (lanes == int(call[len("in.mask_dq("):-1])).astype(float)
             elif call.startswith("in.mask_dqd("):
                 inputs[expr] = (lanes == m + int(call[len("in.mask_dqd("):-1])).astype(float)
+            elif call.startswith("in.mask_row_le("):
+                inputs[expr] = (int(call[len("in.mask_row_le("):-1]) <= kcol).astype(float)
         vals = tr.evaluate(inputs, dtype=dtype)
         assert sum(1 for (dst, _) in tr.outputs if dst == "barrier") == (1 if roles else 0)      # every wave of a block: the same count
         for (dst, _), val in zip(tr.outputs, vals):
             if isinstance(dst, int):
                 val = np.asarray(val) + np.zeros(wave.WAVE)
-                for lane in range(2 * m):
-                    out[first + dst, first + (lane % m) + (n if lane >= m else 0)] = val[lane]
+                if kind == "id":
+                    out[first + dst] = val[0]                              # a wave-uniform value per joint
+                elif kind == "fd":
+                    out[first:first + m] = val[:m]                         # lane k: qdd_k
+                elif kind == "minv":
+                    out[first + dst, first:first + m] = val[:m]            # lane k: column k
+                else:
+                    for lane in range(2 * m):
+                        out[first + dst, first + (lane % m) + (n if lane >= m else 0)] = val[lane]
             elif isinstance(dst, str) and dst.startswith("utab2:"):
                 table_init.setdefault(roles[w], {})[int(dst[6:])] = float(np.asarray(val).reshape(-1)[0])
     return out
@@ -85,6 +98,24 @@ def test_wave_cores_match_the_oracle_on_the_cpu(name, robots, tables):
     assert np.abs(got32 - ref).max() < 2e-4 * np.abs(ref).max()
     plain = interpret_wave_cores(spec, q, qd, u, use_roles=False)       # every wave on its own (no helper): the same numbers
     assert np.abs(plain - ref).max() < 1e-10 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("name", ["iiwa7", "mixed5", "atlas30"])
+def test_wave_cores_of_the_other_algorithms_on_the_cpu(name, robots, tables):
+    """The same phases serve RNEA, Minv, forward dynamics and the RNEA gradient (the small-batch path of every kernel)."""
+    from oracle import rbd_oracle as O
+    spec = RobotSpec(robots(name))
+    n = spec.n
+    q, qd, u = (a[0].astype(np.float64) for a in make_inputs(n, 1, 32))
+    qdd = 0.7 * u
+    T = tables(name)
+    close = lambda got, ref: np.abs(got - ref).max() < 1e-10 * max(1.0, np.abs(ref).max())
+    assert close(interpret_wave_cores(spec, q, qd, u, kind="id"), O.rnea(T, q[None], qd[None])[0][0])
+    assert close(interpret_wave_cores(spec, q, qd, u, kind="id", qdd=qdd), O.rnea(T, q[None], qd[None], qdd[None])[0][0])
+    assert close(interpret_wave_cores(spec, q, qd, u, kind="minv"), np.triu(O.minv(T, q[None])[0]))
+    assert close(interpret_wave_cores(spec, q, qd, u, kind="fd"), O.forward_dynamics(T, q[None], qd[None], u[None])[0])
+    assert close(interpret_wave_cores(spec, q, qd, u, kind="id_du"), O.rnea_grad(T, q[None], qd[None], None)[0])
+    assert close(interpret_wave_cores(spec, q, qd, u, kind="id_du", qdd=qdd), O.rnea_grad(T, q[None], qd[None], qdd[None])[0])
 
 
 def test_wave_groups_are_runs_of_base_trees(robots):
@@ -159,3 +190,72 @@ def test_wave_kernel_on_gpu(robot, tables):
             zero = np.abs(ref["df_du"]).max(axis=0) == 0.0
             assert np.all(outs[0][:, zero] == 0.0)
         h.set_wave(host.ALG_FD_DU, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("robot", ["iiwa7", "mixed5", "atlas30"])
+def test_wave_kernels_of_the_other_algorithms_on_gpu(robot, tables):
+    """RNEA (with and without qdd), Minv, forward dynamics and the RNEA gradient (with and without qdd) through the C ABI with the
+    wave-per-configuration kernels forced, K = 1, 7, 64, 200: against the oracle and against the lane-per-configuration kernels."""
+    import torch
+    from gridcodegenerator_amd import host
+    from test_gpu_parity import TOL, oracle_all, pack
+    from oracle import rbd_oracle as O
+    host.build_library(robot, host.DEFAULT_PRECISION)
+    T = tables(robot)
+    algs = (host.ALG_ID, host.ALG_MINV, host.ALG_FD, host.ALG_ID_DU)
+    with host.GridHandle(robot, device=0, precision=host.DEFAULT_PRECISION) as h:
+        n = h.n
+        for K in (1, 7, 64, 200):
+            q, qd, u = make_inputs(n, K, 60 + K)
+            ref = oracle_all(T, q, qd, u)
+            d_in = torch.from_numpy(pack(q, qd, u)).cuda()
+            qdd_alt = np.random.default_rng(70 + K).uniform(-1.0, 1.0, (K, n)).astype(np.float32)       # (not FD's qdd: RNEA(q, qd, FD(u)) = u cancels)
+            d_qdd = torch.from_numpy(qdd_alt).cuda()
+            q64, qd64, qdd64 = (a.astype(np.float64) for a in (q, qd, qdd_alt))
+            ref["c_qdd"] = O.rnea(T, q64, qd64, qdd64)[0]
+            dc = O.rnea_grad(T, q64, qd64, qdd64)
+            ref["dc_du"] = np.concatenate([O.flat_colmajor(dc[:, :, :n]), O.flat_colmajor(dc[:, :, n:])], axis=1)
+
+            def run_all(blocks=0):
+                res = {}
+                mk = lambda cols: torch.full((K + 2, cols), 4.25, dtype=torch.float32, device="cuda")
+                o = mk(n); h.inverse_dynamics_device(o.data_ptr(), d_in.data_ptr(), 3 * n, K, blocks=blocks); res["c"] = o
+                o = mk(n); h.inverse_dynamics_device(o.data_ptr(), d_in.data_ptr(), 3 * n, K, d_qdd=d_qdd.data_ptr(), blocks=blocks); res["c_qdd"] = o
+                o = mk(n * n); h.direct_minv_device(o.data_ptr(), d_in.data_ptr(), 3 * n, K, blocks=blocks); res["Minv"] = o
+                o = mk(n); h.forward_dynamics_device(o.data_ptr(), d_in.data_ptr(), 3 * n, K, blocks=blocks); res["qdd"] = o
+                o = mk(2 * n * n); h.inverse_dynamics_gradient_device(o.data_ptr(), d_in.data_ptr(), 3 * n, K, blocks=blocks); res["dc_du_noqdd"] = o
+                o = mk(2 * n * n); h.inverse_dynamics_gradient_device(o.data_ptr(), d_in.data_ptr(), 3 * n, K, d_qdd=d_qdd.data_ptr(), blocks=blocks); res["dc_du"] = o
+                h.synchronize()
+                out = {}
+                for k, v in res.items():
+                    v = v.cpu().numpy()
+                    assert np.all(v[K:] == 4.25), k
+                    out[k] = v[:K]
+                return out
+
+            for a in algs:
+                h.set_wave(a, 1)
+            plain = run_all()
+            for a in algs:
+                assert h.wave_available(a)
+                h.set_wave(a, 2)
+                assert h.get_wave(a, K)
+            got = run_all()
+            few = run_all(blocks=3)
+            for a in algs:
+                h.set_wave(a, 0)
+            tol = TOL[robot]
+            for key in got:
+                assert np.array_equal(got[key], few[key]), key
+                t = tol[{"dc_du_noqdd": "dc_du"}.get(key, key)] * (4 if K < 64 else 1)
+                assert relerr(got[key], ref[key])[0] < t, (robot, K, key, relerr(got[key], ref[key])[0])
+                assert relerr(got[key], plain[key].astype(np.float64))[0] < 2 * t, (robot, K, key)
+            # entries that couple different base-rooted trees are written as exact zeros
+            spec = RobotSpec(get_robot(robot))
+            tree = np.zeros(n, dtype=int)
+            for t_id, (first, m) in enumerate(base_trees(spec)):
+                tree[first:first + m] = t_id
+            cross = (tree[:, None] != tree[None, :]).T.reshape(-1)         # column-major (col, row)
+            assert np.all(got["dc_du"][:, np.concatenate([cross, cross])] == 0.0)
+            assert np.all(got["Minv"][:, cross] == 0.0)
