@@ -1,6 +1,6 @@
 """Fold rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py` into profiles/pmc_traffic.json.
 
-usage: python tools/pmc_traffic.py <round> <precision> <fetch counter_collection.csv> <write counter_collection.csv>
+usage: python tools/pmc_traffic.py <round> <precision> <fetch counter_collection.csv> <write counter_collection.csv> [batch=16384]
 
 Entries are keyed "<robot>:<batch>:<kernel name>" and stamped with the sha of the generated header they were measured on
 (bench.py prints `traffic` only when that sha matches the header of the library it runs -- a stale figure cannot be printed).
@@ -31,6 +31,7 @@ def averages(path, counter):
 
 def main():
     rnd, precision, fetch_csv, write_csv = sys.argv[1:5]
+    batch = int(sys.argv[5]) if len(sys.argv) > 5 else 16384
     fetch, write = averages(fetch_csv, "FETCH_SIZE"), averages(write_csv, "WRITE_SIZE")
     path = os.path.join(REPO, "profiles", "pmc_traffic.json")
     with open(path) as fh:
@@ -45,7 +46,7 @@ def main():
             sha = hashlib.sha256(fh.read()).hexdigest()[:16]
         f, nf = fetch[kname]
         w, nw = write[kname]
-        key = "%s:%d:%s" % (robot, 16384, kernel)
+        key = "%s:%d:%s" % (robot, batch, kernel)
         data[key] = {"kernel": kernel, "fetch_kb": round(f, 1), "write_kb": round(w, 1), "bytes": int((f + w) * 1024), "dispatches": [nf, nw],
                      "round": rnd, "precision": precision, "header_sha": sha}
         print(key, data[key])
