@@ -36,3 +36,6 @@ want sweeps && { step ksweep  bash -c "timeout -k 10 300 python tools/ksweep_all
 want sweeps && { step stamps  bash -c "timeout -k 10 120 ./tools/ubench/phase_stamps > $out/phase_stamps.txt 2>&1"; }
 want sweeps && { step pairs   bash -c "timeout -k 10 200 ./tools/ubench/pair_stamps > $out/pair_stamps.txt 2>&1"; }
 find $out -name "*.csv" | head -12
+# the headline kernel alone (the default bench line also runs it on two streams at once, which stretches those dispatches)
+want prof2 && { step kt_headline bash -c "timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/kt_headline --output-format csv -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-secondary > $out/kt_headline.log 2>&1"; }
+exit 0
