@@ -1366,9 +1366,9 @@ class AlgorithmEmitMixin:
             "grid_tile_iter it(NUM_TIMESTEPS);              // lane / wave bookkeeping only: the tile loop below is per BLOCK",
             "T *s_wave = reinterpret_cast<T *>(s_grid_dyn) + it.wave_in_block*%d;" % stage,
             "T *s_xch = reinterpret_cast<T *>(s_grid_dyn) + %d;" % xch_off,
-            "const int nblocks = gridDim.x*gridDim.y*gridDim.z;",
-            "const int bid = blockIdx.x + gridDim.x*(blockIdx.y + gridDim.y*blockIdx.z);",
-            "if (blockDim.x*blockDim.y*blockDim.z != %d){return;}    // (the launcher guarantees it; a wrong shape must not deadlock the barriers)" % (W * WAVE),
+            "const int nblocks = grid_num_blocks();",
+            "const int bid = grid_block_id();",
+            "if (grid_block_threads() != %d){return;}    // (the launcher guarantees it; a wrong shape must not deadlock the barriers)" % (W * WAVE),
             "for (int k0 = bid*GRID_WAVE_SIZE; k0 < NUM_TIMESTEPS; k0 += nblocks*GRID_WAVE_SIZE){",
         ])
         self.indent_level += 1
@@ -1517,12 +1517,12 @@ class AlgorithmEmitMixin:
         self.gen_add_code_lines([
             "extern __shared__ __align__(16) unsigned char s_grid_dyn[];",
             "(void)d_robotModel;",
-            "const int tid = threadIdx.x + blockDim.x*(threadIdx.y + blockDim.y*threadIdx.z);",
+            "const int tid = grid_thread_id();",
             "const int lane = tid & (GRID_WAVE_SIZE - 1);",
             "const int wave = __builtin_amdgcn_readfirstlane(tid / GRID_WAVE_SIZE);",
-            "const int nblocks = gridDim.x*gridDim.y*gridDim.z;",
-            "const int bid = blockIdx.x + gridDim.x*(blockIdx.y + gridDim.y*blockIdx.z);",
-            "if (blockDim.x*blockDim.y*blockDim.z != %d){return;}    // (the launcher guarantees it)" % (W * WAVE),
+            "const int nblocks = grid_num_blocks();",
+            "const int bid = grid_block_id();",
+            "if (grid_block_threads() != %d){return;}    // (the launcher guarantees it)" % (W * WAVE),
             "T *s_w = reinterpret_cast<T *>(s_grid_dyn) + wave*%d;" % per_wave,
             "switch (wave){", ], True)
         for w, (first, m) in enumerate(groups):
@@ -1648,12 +1648,12 @@ class AlgorithmEmitMixin:
             self.gen_add_code_lines([
                 "extern __shared__ __align__(16) unsigned char s_grid_dyn[];",
                 "(void)d_robotModel;",
-                "const int tid = threadIdx.x + blockDim.x*(threadIdx.y + blockDim.y*threadIdx.z);",
+                "const int tid = grid_thread_id();",
                 "const int lane = tid & (GRID_WAVE_SIZE - 1);",
                 "const int wave = __builtin_amdgcn_readfirstlane(tid / GRID_WAVE_SIZE);",
-                "const int nblocks = gridDim.x*gridDim.y*gridDim.z;",
-                "const int bid = blockIdx.x + gridDim.x*(blockIdx.y + gridDim.y*blockIdx.z);",
-                "if (blockDim.x*blockDim.y*blockDim.z != %d){return;}    // (the launcher guarantees it)" % (W * WAVE),
+                "const int nblocks = grid_num_blocks();",
+                "const int bid = grid_block_id();",
+                "if (grid_block_threads() != %d){return;}    // (the launcher guarantees it)" % (W * WAVE),
                 "T *s_w = reinterpret_cast<T *>(s_grid_dyn) + wave*%d;" % per_wave,
                 "switch (wave){", ], True)
             for w, (first, m) in enumerate(groups):

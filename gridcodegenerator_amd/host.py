@@ -229,6 +229,13 @@ def kernel_resources(robot_name, precision="fp32"):
         return parse_kernel_resources(fh.read())
 
 
+# Kernel arguments preloaded into SGPRs at wave launch (gfx950: 16 user SGPRs, 2 of them the kernarg pointer): the explicit arguments
+# of every kernel here (<= 12 dwords) and the first hidden ones (block counts, x / y block extents) need no s_load -- a wave's first
+# memory instruction is the load of its inputs (helpers/_runtime_emit.py: grid_block_threads).  The code object keeps a prologue that
+# loads them the old way on firmware without the feature.
+KERNARG_PRELOAD = ["-mllvm", "-amdgpu-kernarg-preload-count=16"]
+
+
 def generate_header(robot, path, namespace, **gen_kwargs):
     """Run the generator for ``robot`` and move ``<namespace>.hip.h`` (written to the CWD, as the
     reference writes grid.cuh to the CWD, GRiDCodeGenerator.py:308) to ``path``."""
@@ -281,7 +288,7 @@ def _build_library_locked(robot_name, precision, force, verbose, extra_flags, ge
             return "-O3"
         return "-O1"
 
-    flags = ["--offload-arch=" + ARCH, opt, "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-I" + INCLUDE_DIR] + list(extra_flags)
+    flags = ["--offload-arch=" + ARCH, opt, "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-I" + INCLUDE_DIR] + KERNARG_PRELOAD + list(extra_flags)
     # (no absolute paths in the fingerprint: the same tree is mounted at different locations on different boxes)
     robot_obj = get_robot(robot_name)
     model_hash = hashlib.sha256(repr([(robot_obj.get_parent_id(j), robot_obj.get_damping_by_id(j), np.asarray(robot_obj.get_Imat_by_id(j)).tolist(),
@@ -410,7 +417,7 @@ def build_api_harness(robot_name, precision="fp32", force=False):
         with open(out + ".key") as fh:
             if fh.read().strip() == key:
                 return out
-    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O1", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O1", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"] + KERNARG_PRELOAD + [
            "-DGRID_HEADER=\"%s\"" % p["header"], "-DGRID_NS=grid_" + robot_name, "-DGRID_EXTERN_KERNELS", API_HARNESS_SRC,
            "-L" + BUILD_DIR, "-l" + os.path.basename(lib)[3:-3], "-Wl,-rpath,$ORIGIN", "-o", out + ".tmp"]
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
@@ -444,7 +451,7 @@ def build_single_timing_harness(robot_name, precision="fp32", force=False):
         with open(out + ".key") as fh:
             if fh.read().strip() == key:
                 return out
-    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O1", "-ffp-contract=off", "-std=c++17", "-DGRID_HEADER=\"%s\"" % p["header"],
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O1", "-ffp-contract=off", "-std=c++17"] + KERNARG_PRELOAD + ["-DGRID_HEADER=\"%s\"" % p["header"],
            "-DGRID_NS=grid_" + robot_name, SINGLE_TIMING_SRC, "-o", out + ".tmp"]
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if proc.returncode != 0:
