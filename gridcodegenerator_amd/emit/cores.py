@@ -154,6 +154,15 @@ class CoopSlots:
         self.qdd = [base + n + j for j in range(n)]            # qdd = Minv (u - c), or the first producer's share of it
         self.qdd2 = [base + 2 * n + j for j in range(n)]       # the second producer's share (ksplit is not None)
         self.count = base + 3 * n
+        # Wave-private use of the region (recomputing schedule): the accumulated force f_j of a gradient column's joint, parked by the
+        # wave that owns column j and re-read when it reaches the column of j's parent (core_gradient_recompute: f table).  No
+        # barrier involved -- a wave reads only what it wrote itself, and the DS operations of a wave execute in order.
+        self.f = {}
+        self.f_table = True              # (False: every column walks its joint's whole subtree again -- kept for the A/B test)
+        for j in range(n):
+            if spec.parent[j] != -1:
+                self.f[j] = self.count
+                self.count += 6
         # Two producer waves (large robots): both run the backward pass of the Minv recursion, then "producer" finishes the
         # columns k < ksplit of the forward pass and "producer2" the columns k >= ksplit (the forward pass is independent per
         # column); each folds its entries into its own share of qdd.  None: one producer does everything.
@@ -978,7 +987,11 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
             memo[("a", j)] = a
         return memo[("a", j)]
 
+    ftab = {"on": False, "done": set()}     # tile-cooperative cores: f of the wave's own finished columns lives in LDS (CoopSlots.f)
+
     def facc(j):
+        if ("f", j) not in memo and ftab["on"] and j in ftab["done"]:
+            memo[("f", j)] = [tr.tab_get(coop[1].f[j] + r) for r in range(6)]
         if ("f", j) not in memo:
             v = v_of(j)
             f = alg.vadd(alg.matvec(tr, I[j], a_of(j)), alg.fxv(tr, v, alg.matvec(tr, I[j], v)))
@@ -1001,6 +1014,15 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
                 del memo[key]
             for key in [key for key in memo if key[0] in ("X", "v", "xa", "a")]:
                 del memo[key]
+            return f
+        if kind_ == "f" and ftab["on"]:
+            # The accumulated force of a column's joint walks the joint's whole subtree -- unless a child is a column this wave has
+            # already finished (columns run deepest first): its f is then six LDS reads.  Atlas-30: a tenth of a tile's arithmetic.
+            f = facc(j)
+            if j not in ftab["done"] and j in coop[1].f:
+                for r in range(6):
+                    tr.tab_put(coop[1].f[j] + r, f[r])
+                ftab["done"].add(j)
             return f
         return {"v": v_of, "xa": xa_of, "f": facc}[kind_](j)
 
@@ -1076,6 +1098,9 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
         tr.fence()
         tr.cse_release(mark, keep=[t.ref for pair in trig if pair is not None for t in pair] + [v.ref for d in saved_dqd.values() for v in d.values() if not isinstance(v.ref, float)])
         memo.clear()
-        order = hoist + [c for c in cols if c not in hoist]        # the parked columns first: their registers are freed early
+        # the parked columns first (their registers are freed early), and within both runs the deepest first: a column's accumulated
+        # force then finds its children's in the f table (DFS pre-order ids: children have larger ids)
+        order = sorted(hoist, reverse=True) + sorted((c for c in cols if c not in hoist), reverse=True)
+        ftab["on"] = bool(slots.f_table)
     alg.rnea_grad_columns(tr, spec, I, q, qd, trig, loader, emit_column, order=order, prefetch=0, xof=Xof, keep=keep)
     return tr

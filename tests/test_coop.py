@@ -219,3 +219,28 @@ def test_coop_kernel_full_size_iiwa7_16384(tables):
         h.forward_dynamics_gradient_device(d_out_p.data_ptr(), d_in_p.data_ptr(), 3 * n, K)
         h.synchronize()
         assert np.array_equal(d_out_p.cpu().numpy(), df[perm])
+
+
+def test_f_table_replaces_subtree_walks(robots):
+    """Recomputing schedule, tile-cooperative cores: a wave parks the accumulated force of every column joint it finishes in its
+    own exchange slots (CoopSlots.f) and runs its columns deepest first, so the force of a column's joint is its local part plus
+    six LDS reads per child column instead of a walk over the whole subtree.  Same outputs (emulate_block tests above), less
+    arithmetic after the second barrier; slots are written once, before they are read, and only by the wave that reads them."""
+    spec = RobotSpec(robots("atlas30"))
+    arith = ("fma", "mul", "add")
+
+    def after_barriers(f_table, role, cols):
+        slots = cores.CoopSlots(spec)
+        slots.ksplit = 15
+        slots.f_table = f_table
+        tr = cores.core_gradient_recompute(spec, "fd", cols=cols, coop=(role, slots))
+        live = tr.live_nodes()
+        b = [pos for (dst, _), pos in zip(tr.outputs, tr.out_pos) if dst == "barrier"]
+        puts = [int(d[4:]) for (d, _) in tr.outputs if isinstance(d, str) and d.startswith("tab:")]
+        return sum(1 for k in range(b[1], len(tr.nodes)) if live[k] and tr.nodes[k][0] in arith), puts, slots
+    for role, cols in (("consumer", [3, 4, 5, 6, 7, 8, 9]), ("producer2", [10, 11, 12, 13, 14, 15, 16])):
+        with_table, puts, slots = after_barriers(True, role, cols)
+        without, no_puts, _ = after_barriers(False, role, cols)
+        assert no_puts == [] and with_table < 0.93 * without, (role, with_table, without)
+        assert sorted(puts) == sorted(slots.f[j] + r for j in cols for r in range(6))       # every column joint, once
+    assert 4 * (4 * 64 * 32 + 64 * cores.CoopSlots(spec).count) <= 160 * 1024                # staging + exchange region fit the CU's LDS
