@@ -5,7 +5,7 @@
 set -o pipefail
 export TMPDIR=/tmp
 out=$1; mkdir -p $out
-for K in 64 4096 16384 65536; do
+for K in ${GRID_PMC_KS:-64 4096 16384 65536}; do
   i=0
   for ctrs in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
               "SQ_INST_CYCLES_VMEM_WR SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_WR SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL" \
