@@ -1191,20 +1191,17 @@ class AlgorithmEmitMixin:
             if slots.hoist_budget:      # the wave with the heaviest (earliest) columns has the whole idle time to park some of them:
                 return "consumer_c" if i == 1 else "consumer"       # the next one computes and publishes c
             return "consumer_c" if i == 0 else "consumer"
-        def timeline(role, cols):
-            # (instruction slots before the first barrier, between the barriers, after the second): arithmetic + exchange-region
-            # reads, + the flushes of the wave's columns in the last phase
+        def ops(role, cols):
+            # what decides the block's time is the work AFTER the second barrier: every wave leaves it at the same moment (when the
+            # producer has published qdd), so the block finishes with the wave that has the most phase-2 instructions
+            # (arithmetic + exchange-region reads issued after the barrier)
             tr = builder(role, cols, slots)
             live = tr.live_nodes()
-            b = [pos for (dst, _), pos in zip(tr.outputs, tr.out_pos) if dst == "barrier"]
+            barriers = [pos for (dst, _), pos in zip(tr.outputs, tr.out_pos) if dst == "barrier"]
+            start = barriers[-1]
             arith = ("fma", "mul", "add", "pkfma", "pkmul", "pkadd")
-            cnt = lambda lo, hi: sum(1 for k in range(lo, hi) if live[k] and (
+            return self.FLUSH_SLOTS_PER_COLUMN * len(cols) + sum(1 for k in range(start, len(tr.nodes)) if live[k] and (
                 tr.nodes[k][0] in arith or (tr.nodes[k][0] == "in" and str(tr.nodes[k][1]).startswith("in.xch_get("))))
-            return (cnt(1, b[0]), cnt(b[0], b[-1]), self.FLUSH_SLOTS_PER_COLUMN * len(cols) + cnt(b[-1], len(tr.nodes)))
-
-        def ops(role, cols):
-            # first guess: what a wave has left AFTER the second barrier (every wave leaves it at the same moment)
-            return timeline(role, cols)[2]
         single = {role: [ops(role, [c]) for c in range(n)] for role in ("producer", "consumer")}
         base = {role: min(single[role]) for role in single}
         marg = {role: [x - base[role] for x in single[role]] for role in single}
@@ -1228,17 +1225,14 @@ class AlgorithmEmitMixin:
         def cost_exact(i, pr):
             key = (role_of(i), pr)
             if key not in exact:
-                exact[key] = timeline(role_of(i), list(range(*pr)))
+                exact[key] = ops(role_of(i), list(range(*pr)))
             return exact[key]
         # coordinate descent on the W-1 cut points (moves of one or two columns; a move may first make the maximum worse for a
-        # neighbour that a later move relieves, so ties are broken by the sum of squares of the last phase).  The block's time:
-        # every wave leaves a barrier when the LAST one reaches it, so it is the sum over the three phases of the slowest wave's
-        # share -- parked d/dqd recursions count where they run (a consumer that parks more than the producers' passes last
-        # holds the whole block at the barrier)
+        # neighbour that a later move relieves, so ties on the maximum are broken by the sum of squares)
         def score(pp):
             cs = [cost_exact(i, pp[i]) for i in range(W)]
-            return (sum(max(c[ph] for c in cs) for ph in range(3)), sum(c[2] * c[2] for c in cs))
-        for _ in range(40 if n > 8 else 0):
+            return (max(cs), sum(c * c for c in cs))
+        for _ in range(12 if n > 8 else 0):
             cur = score(parts)
             best_move = None
             for cut in range(1, W):
@@ -1255,7 +1249,6 @@ class AlgorithmEmitMixin:
                 break
             parts = best_move[1]
         order = [W - 1] + ([W - 2] if two else []) + [i for i in range(W - 1) if not (two and i == W - 2)]      # producer(s) first
-        self.coop_timeline = [cost_exact(i, parts[i]) for i in order] if n > 8 else None
         return [(role_name(i), list(range(*parts[i]))) for i in order]
 
     def _coop_prefix_split(self, builder, slots):
@@ -1311,20 +1304,16 @@ class AlgorithmEmitMixin:
                 # arithmetic (the wave that publishes c has RNEA to do first)
                 arith = ("fma", "mul", "add", "pkfma", "pkmul", "pkadd")
 
-                def phases(role, cols):
+                def before_first_barrier(role, cols):
                     tr = builder(role, cols, slots)
                     live = tr.live_nodes()
-                    b = [pos for (dst, _), pos in zip(tr.outputs, tr.out_pos) if dst == "barrier"]
-                    return [sum(1 for k in range(lo, hi) if live[k] and tr.nodes[k][0] in arith) for (lo, hi) in ((1, b[0]), (b[0], b[1]))]
-                before_first_barrier = lambda role, cols: phases(role, cols)[0]
+                    b0 = [pos for (dst, _), pos in zip(tr.outputs, tr.out_pos) if dst == "barrier"][0]
+                    return sum(1 for k in range(1, b0) if live[k] and tr.nodes[k][0] in arith)
                 rnea_ops = before_first_barrier("consumer_c", [])
                 slots.hoist_cost = [1] * n
                 slots.hoist_budget = {"consumer": 10 ** 9}
                 slots.hoist_cost = [before_first_barrier("consumer", [c]) for c in range(n)]
-                # the two windows: the producers' backward pass (up to the first barrier, where they need c) and their forward pass
-                prod = [phases(r, []) for r in (("producer", "producer2") if slots.ksplit is not None else ("producer",))]
-                win1, win2 = max(p[0] for p in prod), max(p[1] for p in prod)
-                slots.hoist_budget = {"consumer": (int(win1), int(win2)), "consumer_c": (int(0.9 * max(0, win1 - rnea_ops)), int(win2))}
+                slots.hoist_budget = {"consumer": int(prefix), "consumer_c": int(0.9 * max(0, prefix - rnea_ops))}
         else:
             builder = lambda role, cols, sl: cores.core_forward_dynamics_gradient_coop(self.spec, role, cols, sl, hoist=self.coop_hoist)
         groups = self._coop_groups_fused(builder, slots) if (self.coop_hoist and not rec) else self._coop_groups(builder, slots)

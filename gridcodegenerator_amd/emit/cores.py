@@ -168,36 +168,23 @@ class CoopSlots:
         # column); each folds its entries into its own share of qdd.  None: one producer does everything.
         self.ksplit = None
         # Consumer waves idle while the producers run the Minv recursion.  The d/dqd half of a gradient column needs neither qdd
-        # nor Minv before its final product, so a consumer computes it for some of its columns AHEAD of the second barrier and
-        # keeps the n values per column in registers.  Two windows, because the producers need c at the FIRST barrier (it sits
-        # between the two passes of their recursion): work parked before it must not outlast the producers' backward pass, the
-        # rest goes between the barriers, next to the producers' forward pass.  hoist_budget[role] = (arithmetic instructions
-        # before the first barrier, between the barriers), hoist_cost[col] = what the d/dqd recursion of that column costs
-        # (None: no hoisting).  (Round 2 parked everything before the first barrier against the length of the WHOLE prefix: the
-        # consumers reached the first barrier 1.4 k instructions after the producers of Atlas-30 and the whole block waited.)
+        # nor Minv before its final product, so a consumer computes it for some of its columns BEFORE the first barrier and keeps
+        # the n values per column in registers: hoist_budget[role] = arithmetic instructions of idle time to fill,
+        # hoist_cost[col] = what the d/dqd recursion of that column costs (None: no hoisting).
         self.hoist_budget = None
         self.hoist_cost = None
         self.hoist_max_columns = 4       # n parked values per column stay in registers across the barriers
-        self.hoist_overfill = 1.3        # a column may overrun what is left of the second window by this factor: the block then
-                                         # waits for it, but the wave that parks it is the one with the most work behind the barriers
 
     def hoisted_columns(self, role, cols):
-        """(columns whose d/dqd recursion this role runs before the first barrier, columns it runs between the barriers): the
-        most expensive first, each into the first window it fits in."""
+        """The columns of `cols` whose d/dqd recursion this role runs ahead of the barriers: cheapest first while the budget lasts."""
         if not self.hoist_budget or role not in self.hoist_budget or not cols:
-            return [], []
-        budget = self.hoist_budget[role]
-        if not isinstance(budget, tuple):
-            budget = (budget, 0)
-        left = [budget[0], budget[1]]
-        picked = ([], [])
-        for c in sorted(cols, key=lambda c: -self.hoist_cost[c]):
-            if len(picked[0]) + len(picked[1]) >= self.hoist_max_columns:
+            return []
+        left, picked = self.hoist_budget[role], []
+        for c in sorted(cols, key=lambda c: self.hoist_cost[c]):
+            if self.hoist_cost[c] > left or len(picked) >= self.hoist_max_columns:
                 break
-            if self.hoist_cost[c] <= left[0]:
-                picked[0].append(c); left[0] -= self.hoist_cost[c]
-            elif self.hoist_cost[c] <= left[1] or (left[1] == budget[1] and 0 < budget[1] and self.hoist_cost[c] <= self.hoist_overfill * left[1]):
-                picked[1].append(c); left[1] -= self.hoist_cost[c]
+            picked.append(c)
+            left -= self.hoist_cost[c]
         return picked
 
     def entry(self, tr, r, k):
@@ -209,7 +196,7 @@ class CoopSlots:
 COOP_ROLES = ("producer", "producer2", "consumer_c", "consumer")
 
 
-def _coop_prologue(tr, spec, slots, role, X, I, qd, u, g, demand_order=True, pre_barrier=None, mid_barrier=None):
+def _coop_prologue(tr, spec, slots, role, X, I, qd, u, g, demand_order=True, pre_barrier=None):
     """Phases 1 and 2 of a tile-cooperative core; returns qdd (read from the exchange region by every wave).
 
     producer:  backward pass of the Minv recursion | barrier | c from the exchange region; forward pass: every entry of Minv is
@@ -262,8 +249,6 @@ def _coop_prologue(tr, spec, slots, role, X, I, qd, u, g, demand_order=True, pre
         if pre_barrier is not None:
             pre_barrier()                # (consumers: work that needs neither Minv nor qdd, done while the producers are busy)
         tr.barrier()
-        if mid_barrier is not None:
-            mid_barrier()                # (... and more of it next to the producers' forward pass)
         tr.barrier()
     if two:
         return [tr.xch_get(slots.qdd[j]) + tr.xch_get(slots.qdd2[j]) for j in range(n)]
@@ -1097,25 +1082,19 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
         # phases 1 and 2 of the block (_coop_prologue).  A consumer fills its idle time with the d/dqd recursions of some of its
         # columns (CoopSlots.hoisted_columns): they need neither qdd nor Minv; the n values per column stay in registers until
         # the column's products after the second barrier.
-        hoist_pre, hoist_mid = slots.hoisted_columns(role, list(cols)) if role in ("consumer", "consumer_c") else ([], [])
-        hoist = hoist_pre + hoist_mid
+        hoist = slots.hoisted_columns(role, list(cols)) if role in ("consumer", "consumer_c") else []
 
-        def park(which):
+        def pre_barrier():
             def capture(col, dc):
                 memo.clear()
                 saved_dqd[col] = {k: dc[k][1] for k in dc}
                 for v in saved_dqd[col].values():
                     tr.anchor(v)
-            alg.rnea_grad_columns(tr, spec, I, q, qd, trig, loader, capture, order=which, prefetch=0, xof=Xof,
-                                  keep=keep + [v.ref for d in saved_dqd.values() for v in d.values() if not isinstance(v.ref, float)])
-            memo.clear()
-        pre_barrier = lambda: park(hoist_pre)
-        mid_barrier = lambda: park(hoist_mid)
+            alg.rnea_grad_columns(tr, spec, I, q, qd, trig, loader, capture, order=hoist, prefetch=0, xof=Xof, keep=keep)
         mark = tr.cse_mark()
         u = [tr.inp("in.u(%d)" % j) for j in range(n)]
         X = alg.build_X(tr, spec, q, trig)
-        qdd = list(_coop_prologue(tr, spec, slots, role, X, I, qd, u, g, demand_order=False, pre_barrier=pre_barrier if hoist_pre else None,
-                                  mid_barrier=mid_barrier if hoist_mid else None))
+        qdd = list(_coop_prologue(tr, spec, slots, role, X, I, qd, u, g, demand_order=False, pre_barrier=pre_barrier if hoist else None))
         tr.fence()
         tr.cse_release(mark, keep=[t.ref for pair in trig if pair is not None for t in pair] + [v.ref for d in saved_dqd.values() for v in d.values() if not isinstance(v.ref, float)])
         memo.clear()
