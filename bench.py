@@ -371,7 +371,10 @@ def main():
         w1.prewarm(min(args.prewarm_s, 0.2))
         secondary["iiwa7_batch16384_two_streams"] = w1.measure(sharding, dist, args.steps, args.warmup, world, reduce_device)
         w1.close()
-        plan = [("atlas30_batch16384", "atlas30", 16384, min(args.steps, 50), min(args.warmup, 5))]
+        # ... Atlas-30 at batch 16k, and its small-batch path (64 configurations, dispatched to the
+        # wave-per-configuration kernel -- `ms_per_step` is the latency of one dependent launch)
+        plan = [("atlas30_batch16384", "atlas30", 16384, min(args.steps, 50), min(args.warmup, 5)),
+                ("atlas30_batch64_small_batch_path", "atlas30", 64, min(args.steps, 50), min(args.warmup, 5))]
         if world > 1:
             plan.append(("atlas30_batch131072_per_gpu", "atlas30", 131072, min(args.steps, 10), min(args.warmup, 2)))
         for (key, robot, K, steps, warmup) in plan:
