@@ -376,6 +376,31 @@ class Tracer:
             acc = self.fma(a, b, acc)
         return acc
 
+    def dots(self, chains, inits=None):
+        """Several independent dot products created in LOCKSTEP: term t of every chain before term t + 1 of any.  Same values as
+        [dot(c) for c in chains] (each chain keeps its own order of accumulation, so results are bit-identical); what changes is
+        the creation order and with it -- in the creation-order emission of the large-robot cores -- the instruction order: a
+        dependent fma can issue only ~9 cycles after its predecessor, an independent one after 4, and hipcc at -O1 leaves a chain
+        where the source put it (profiles/r03/coop_stamps_atlas30.txt: the forward pass of the Minv recursion ran at 12 cycles
+        per instruction)."""
+        if self.dot_ways > 1:
+            return [self.dot(c, init=(inits[i] if inits is not None else None)) for i, c in enumerate(chains)]
+        lifted = []
+        for c in chains:
+            l = []
+            for (a, b) in c:
+                a = a if isinstance(a, (V, P)) else V(self, float(a))
+                b = b if isinstance(b, (V, P)) else V(self, float(b))
+                if not (a.is_zero() or b.is_zero()):
+                    l.append((a, b))
+            lifted.append(l)
+        accs = [(inits[i] if (inits is not None and inits[i] is not None) else V(self, 0.0)) for i in range(len(chains))]
+        for t in range(max([len(l) for l in lifted] + [0])):
+            for i, l in enumerate(lifted):
+                if t < len(l):
+                    accs[i] = self.fma(l[t][0], l[t][1], accs[i])
+        return accs
+
     def rcp(self, a):
         if isinstance(a.ref, float):
             return V(self, 1.0 / a.ref)
