@@ -443,8 +443,15 @@ class Tracer:
         self._xch_serial = getattr(self, "_xch_serial", 0) + 1
         return self.inp("in.xch_get(%d)/*%d*/" % (slot, self._xch_serial))
 
-    def barrier(self):
-        """Block barrier at this point of the core (every wave of the block executes exactly the same number of them)."""
+    def barrier(self, kind=0):
+        """Synchronisation point of a tile-cooperative core (every wave of the block records the same number of them, in the same
+        order).  kind 0: block barrier.  The FIRST point of the forward-dynamics-gradient cores only has to order "c is published"
+        before "the producers read c", so only the waves concerned pay for it: kind 1 = wait until c is published (producers),
+        kind 2 = signal that it is (the wave that computes c), kind 3 = nothing (the other consumers).  (barrier_kinds[i] belongs to
+        the i-th "barrier" output.)"""
+        if not hasattr(self, "barrier_kinds"):
+            self.barrier_kinds = []
+        self.barrier_kinds.append(int(kind))
         self.out("barrier", 0.0)
 
     def anchor(self, val):
