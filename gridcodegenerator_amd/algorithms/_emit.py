@@ -101,23 +101,7 @@ class AlgorithmEmitMixin:
             "template <typename T, typename C, typename In, typename Out>",
             "__host__ __device__ __forceinline__",
             "void %s(const In &in, Out &out, const T gravity)" % name, tracer,
-            store=self._sync_aware_store(tracer, fence_after_store), order=order, fence_stmt=fence_stmt)
-
-    def _sync_aware_store(self, tracer, fence_after_store):
-        """_core_store, with the synchronisation points of a tile-cooperative core emitted by kind (Tracer.barrier)."""
-        kinds = list(getattr(tracer, "barrier_kinds", []))
-        seen = [0]
-        text = {1: "GRID_SCHED_FENCE(); in.wait_c(); GRID_SCHED_FENCE();", 2: "GRID_SCHED_FENCE(); in.signal_c(); GRID_SCHED_FENCE();",
-                3: "GRID_SCHED_FENCE();     // (first synchronisation point of the block: nothing to wait for in this wave)"}
-
-        def store(dst, val):
-            if dst == "barrier":
-                kind = kinds[seen[0]] if seen[0] < len(kinds) else 0
-                seen[0] += 1
-                if kind:
-                    return text[kind]
-            return self._core_store(dst, val, fence_after_store)
-        return store
+            store=lambda dst, val: self._core_store(dst, val, fence_after_store), order=order, fence_stmt=fence_stmt)
 
     @staticmethod
     def _core_store(dst, val, fence_after_store):
@@ -1323,8 +1307,8 @@ class AlgorithmEmitMixin:
                 def before_first_barrier(role, cols):
                     tr = builder(role, cols, slots)
                     live = tr.live_nodes()
-                    b1 = [pos for (dst, _), pos in zip(tr.outputs, tr.out_pos) if dst == "barrier"][-1]     # (parked work runs up to the LAST synchronisation point)
-                    return sum(1 for k in range(1, b1) if live[k] and tr.nodes[k][0] in arith)
+                    b0 = [pos for (dst, _), pos in zip(tr.outputs, tr.out_pos) if dst == "barrier"][0]
+                    return sum(1 for k in range(1, b0) if live[k] and tr.nodes[k][0] in arith)
                 rnea_ops = before_first_barrier("consumer_c", [])
                 slots.hoist_cost = [1] * n
                 slots.hoist_budget = {"consumer": 10 ** 9}
@@ -1385,16 +1369,13 @@ class AlgorithmEmitMixin:
             "const int nblocks = grid_num_blocks();",
             "const int bid = grid_block_id();",
             "if (grid_block_threads() != %d){return;}    // (the launcher guarantees it; a wrong shape must not deadlock the barriers)" % (W * WAVE),
-            "int *s_flag = reinterpret_cast<int *>(s_xch + %d);        // \"c is published\" tag of the current tile (grid_in_coop::wait_c)" % (WAVE * slots.c_flag_slot),
-            "*(volatile int *)s_flag = -1;",
-            "grid_block_sync();",
             "for (int k0 = bid*GRID_WAVE_SIZE; k0 < NUM_TIMESTEPS; k0 += nblocks*GRID_WAVE_SIZE){",
         ])
         self.indent_level += 1
         self.gen_add_code_line("T s_q_qd_u[%d];" % (3 * n))
         self._emit_load("s_q_qd_u", "d_q_qd_u", 3 * n, "stride_q_qd_u", piece)
         self.gen_add_code_line("const grid_in_coop<T> in = {s_q_qd_u, s_q_qd_u + %d, s_q_qd_u + %d, s_xch, it.lane, "
-                               "(unsigned)reinterpret_cast<unsigned long long>(s_xch) + (unsigned)sizeof(T)*it.lane, s_flag, k0};" % (n, 2 * n))
+                               "(unsigned)reinterpret_cast<unsigned long long>(s_xch) + (unsigned)sizeof(T)*it.lane};" % (n, 2 * n))
         self.gen_add_code_line("switch (it.wave_in_block){", True)
         for w, (cname, cols) in enumerate(names):
             if not cols:        # a producer without gradient columns: Minv and qdd only

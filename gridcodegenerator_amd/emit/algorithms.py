@@ -35,22 +35,20 @@ def vsub(a, b):
     return [x - y for x, y in zip(a, b)]
 
 
-# 6x6 times 6-vector: the six output rows are independent chains, created in lockstep (Tracer.dots: same values, instruction-level
-# parallelism for a wave that issues a dependent fma only every ~9 cycles)
 def matvec(tr, M, v):
-    return tr.dots([[(M[r][c], v[c]) for c in range(6)] for r in range(6)])
+    return [tr.dot([(M[r][c], v[c]) for c in range(6)]) for r in range(6)]
 
 
 def matvec_acc(tr, M, v, acc):
-    return tr.dots([[(M[r][c], v[c]) for c in range(6)] for r in range(6)], inits=list(acc))
+    return [tr.dot([(M[r][c], v[c]) for c in range(6)], init=acc[r]) for r in range(6)]
 
 
 def mattvec(tr, M, v):
-    return tr.dots([[(M[r][c], v[r]) for r in range(6)] for c in range(6)])
+    return [tr.dot([(M[r][c], v[r]) for r in range(6)]) for c in range(6)]
 
 
 def mattvec_acc(tr, M, v, acc):
-    return tr.dots([[(M[r][c], v[r]) for r in range(6)] for c in range(6)], inits=list(acc))
+    return [tr.dot([(M[r][c], v[r]) for r in range(6)], init=acc[c]) for c in range(6)]
 
 
 def mxS(tr, s, vec, alpha=None):
@@ -222,13 +220,12 @@ def _direct_minv(tr, spec, X, I, between=None, on_final=None):
         p, s = spec.parent[j], spec.S_ind[j]
         if p != -1:
             UX = mattvec(tr, X[j], U[j])
-            ks = [k for k in range(j, n) if Fn.get((p, k)) is not None]
-            for g0 in range(0, len(ks), 6):                  # (six columns at a time in lockstep: Tracer.dots)
-                grp = ks[g0:g0 + 6]
-                dd = tr.dots([[(UX[r], Fn[(p, k)][r]) for r in range(6)] for k in grp])
-                for k, d in zip(grp, dd):
-                    corr = Dinv[j] * d
-                    Minv[j][k] = (Minv[j][k] if Minv[j][k] is not None else tr.zero()) - corr
+            for k in range(j, n):
+                Fpk = Fn.get((p, k))
+                if Fpk is None:
+                    continue
+                corr = Dinv[j] * tr.dot([(UX[r], Fpk[r]) for r in range(6)])
+                Minv[j][k] = (Minv[j][k] if Minv[j][k] is not None else tr.zero()) - corr
         for k in range(j, n):
             if Minv[j][k] is None:
                 Minv[j][k] = tr.zero()

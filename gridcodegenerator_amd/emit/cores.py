@@ -154,9 +154,6 @@ class CoopSlots:
         self.qdd = [base + n + j for j in range(n)]            # qdd = Minv (u - c), or the first producer's share of it
         self.qdd2 = [base + 2 * n + j for j in range(n)]       # the second producer's share (ksplit is not None)
         self.count = base + 3 * n
-        self.c_flag = True          # first synchronisation point = "c is published" flag (slot c_flag_slot, word 0) instead of a block barrier
-        self.c_flag_slot = self.count
-        self.count += 1
         # Wave-private use of the region (recomputing schedule): the accumulated force f_j of a gradient column's joint, parked by the
         # wave that owns column j and re-read when it reaches the column of j's parent (core_gradient_recompute: f table).  No
         # barrier involved -- a wave reads only what it wrote itself, and the DS operations of a wave execute in order.
@@ -223,7 +220,7 @@ def _coop_prologue(tr, spec, slots, role, X, I, qd, u, g, demand_order=True, pre
             if demand_order:             # demand-order emission: the backward pass must be issued BEFORE the wave waits
                 for val in carried:      # (creation-order emission places the barrier where it is traced)
                     tr.anchor(val)
-            tr.barrier(1 if slots.c_flag else 0)      # (the producers need c from here on)
+            tr.barrier()
             with tr.mixed_region():
                 state["umc"] = [u[j] - tr.xch_get(slots.c[j]) for j in range(n)]
                 state["acc"] = [tr.zero() for _ in range(n)]
@@ -249,17 +246,9 @@ def _coop_prologue(tr, spec, slots, role, X, I, qd, u, g, demand_order=True, pre
                     tr.xch_put(slots.c[j], c[j])
                 else:
                     tr.anchor(c[j])
-        if slots.c_flag:
-            # c is published: tell the producers, and go on with work that needs neither Minv nor qdd while they are busy.  (Until
-            # round 3 this was a block barrier AFTER that work: the producers of Atlas-30 reached it after 12.5 k cycles and waited
-            # another 13 k for the consumers' parked recursions, profiles/r03/coop_stamps_atlas30.txt.)
-            tr.barrier(2 if role == "consumer_c" else 3)
-            if pre_barrier is not None:
-                pre_barrier()
-        else:
-            if pre_barrier is not None:
-                pre_barrier()            # (consumers: work that needs neither Minv nor qdd, done while the producers are busy)
-            tr.barrier()
+        if pre_barrier is not None:
+            pre_barrier()                # (consumers: work that needs neither Minv nor qdd, done while the producers are busy)
+        tr.barrier()
         tr.barrier()
     if two:
         return [tr.xch_get(slots.qdd[j]) + tr.xch_get(slots.qdd2[j]) for j in range(n)]

@@ -376,31 +376,6 @@ class Tracer:
             acc = self.fma(a, b, acc)
         return acc
 
-    def dots(self, chains, inits=None):
-        """Several independent dot products created in LOCKSTEP: term t of every chain before term t + 1 of any.  Same values as
-        [dot(c) for c in chains] (each chain keeps its own order of accumulation, so results are bit-identical); what changes is
-        the creation order and with it -- in the creation-order emission of the large-robot cores -- the instruction order: a
-        dependent fma can issue only ~9 cycles after its predecessor, an independent one after 4, and hipcc at -O1 leaves a chain
-        where the source put it (profiles/r03/coop_stamps_atlas30.txt: the forward pass of the Minv recursion ran at 12 cycles
-        per instruction)."""
-        if self.dot_ways > 1:
-            return [self.dot(c, init=(inits[i] if inits is not None else None)) for i, c in enumerate(chains)]
-        lifted = []
-        for c in chains:
-            l = []
-            for (a, b) in c:
-                a = a if isinstance(a, (V, P)) else V(self, float(a))
-                b = b if isinstance(b, (V, P)) else V(self, float(b))
-                if not (a.is_zero() or b.is_zero()):
-                    l.append((a, b))
-            lifted.append(l)
-        accs = [(inits[i] if (inits is not None and inits[i] is not None) else V(self, 0.0)) for i in range(len(chains))]
-        for t in range(max([len(l) for l in lifted] + [0])):
-            for i, l in enumerate(lifted):
-                if t < len(l):
-                    accs[i] = self.fma(l[t][0], l[t][1], accs[i])
-        return accs
-
     def rcp(self, a):
         if isinstance(a.ref, float):
             return V(self, 1.0 / a.ref)
@@ -443,15 +418,8 @@ class Tracer:
         self._xch_serial = getattr(self, "_xch_serial", 0) + 1
         return self.inp("in.xch_get(%d)/*%d*/" % (slot, self._xch_serial))
 
-    def barrier(self, kind=0):
-        """Synchronisation point of a tile-cooperative core (every wave of the block records the same number of them, in the same
-        order).  kind 0: block barrier.  The FIRST point of the forward-dynamics-gradient cores only has to order "c is published"
-        before "the producers read c", so only the waves concerned pay for it: kind 1 = wait until c is published (producers),
-        kind 2 = signal that it is (the wave that computes c), kind 3 = nothing (the other consumers).  (barrier_kinds[i] belongs to
-        the i-th "barrier" output.)"""
-        if not hasattr(self, "barrier_kinds"):
-            self.barrier_kinds = []
-        self.barrier_kinds.append(int(kind))
+    def barrier(self):
+        """Block barrier at this point of the core (every wave of the block executes exactly the same number of them)."""
         self.out("barrier", 0.0)
 
     def anchor(self, val):

@@ -98,9 +98,9 @@ def test_parked_dqd_recursions_match_oracle(robot_name, robots, tables):
     assert relerr(got, ref)[0] < 5e-6
     assert np.abs(got - plain).max() <= 1e-6 * np.abs(ref).max()           # (same arithmetic, emitted earlier)
 
-    def before_first_barrier(tr):        # (= ahead of the block barrier: the first synchronisation point is the "c is published" flag)
+    def before_first_barrier(tr):
         live = tr.live_nodes()
-        b0 = [pos for (dst, _), pos in zip(tr.outputs, tr.out_pos) if dst == "barrier"][-1]
+        b0 = [pos for (dst, _), pos in zip(tr.outputs, tr.out_pos) if dst == "barrier"][0]
         return sum(1 for k in range(1, b0) if live[k] and tr.nodes[k][0] in ("fma", "mul", "add"))
     for t0, t1, (role, cols) in zip(tr0, tr1, groups):
         if role.startswith("consumer") and cols:

@@ -252,36 +252,3 @@ def test_optimal_column_sets(setup):
     ref = O.fd_grad(T, q, qd, u)
     want = np.concatenate([ref[:, :, c] for c in cols] + [ref[:, :, spec.n + c] for c in cols], axis=1)
     assert relerr(got, want)[0] < 1e-12
-
-
-def test_lockstep_dot_chains_are_the_same_values_in_another_order():
-    """Tracer.dots: several independent dot products created term by term in lockstep (instruction-level parallelism for the
-    creation-order emission of the large-robot cores) -- every chain keeps its own order of accumulation, so the values are those of
-    Tracer.dot bit for bit, zero terms vanish the same way, and consecutive nodes belong to different chains."""
-    from gridcodegenerator_amd.emit.trace import Tracer
-    rng = np.random.default_rng(5)
-    K = 7
-    vals = {("a", i, j): rng.standard_normal(K) for i in range(4) for j in range(6)}
-    vals.update({("b", j): rng.standard_normal(K) for j in range(6)})
-
-    def build(lockstep):
-        tr = Tracer()
-        a = [[tr.inp("a%d_%d" % (i, j)) if (i + j) % 4 else tr.zero() for j in range(6)] for i in range(4)]     # (some structural zeros)
-        b = [tr.inp("b%d" % j) for j in range(6)]
-        init = [tr.inp("a0_1") * 0.5, None, tr.const(2.0), None]
-        chains = [[(a[i][j], b[j]) for j in range(6)] for i in range(4)]
-        res = tr.dots(chains, inits=init) if lockstep else [tr.dot(c, init=init[i]) for i, c in enumerate(chains)]
-        for i, r in enumerate(res):
-            tr.out(i, r)
-        inputs = {"b%d" % j: vals[("b", j)] for j in range(6)}
-        inputs.update({"a%d_%d" % (i, j): vals[("a", i, j)] for i in range(4) for j in range(6)})
-        return tr, [np.broadcast_to(o, (K,)) for o in tr.evaluate(inputs, dtype="float32")]
-    t0, plain = build(False)
-    t1, lock = build(True)
-    for p, l in zip(plain, lock):
-        assert np.array_equal(p, l)
-    fmas = [k for k in range(1, len(t1.nodes)) if t1.nodes[k][0] == "fma"]
-    chained = sum(1 for k in fmas[1:] if abs(t1.nodes[k][3]) == k - 1)        # accumulator = the node created just before
-    assert chained <= len(fmas) // 4, (chained, len(fmas))
-    fmas0 = [k for k in range(1, len(t0.nodes)) if t0.nodes[k][0] == "fma"]
-    assert sum(1 for k in fmas0[1:] if abs(t0.nodes[k][3]) == k - 1) >= len(fmas0) // 2
