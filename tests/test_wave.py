@@ -259,3 +259,44 @@ def test_wave_kernels_of_the_other_algorithms_on_gpu(robot, tables):
             cross = (tree[:, None] != tree[None, :]).T.reshape(-1)         # column-major (col, row)
             assert np.all(got["dc_du"][:, np.concatenate([cross, cross])] == 0.0)
             assert np.all(got["Minv"][:, cross] == 0.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("robot", ["iiwa7", "atlas30"])
+def test_automatic_choice_follows_the_header_thresholds(robot, tables):
+    """The C ABI picks the wave-per-configuration kernel of an algorithm exactly up to <ALG>_WAVE_AUTO_MAX_K of the generated header
+    (0: never by itself), an explicit choice of another variant wins, and a batch AT the threshold computed through the automatic
+    path agrees with the oracle (forward dynamics and its gradient: the two algorithms with a threshold for large robots)."""
+    import re
+    import torch
+    from gridcodegenerator_amd import host
+    from test_gpu_parity import TOL, oracle_all, pack
+    host.build_library(robot, host.DEFAULT_PRECISION)
+    with open(host.library_paths(robot, host.DEFAULT_PRECISION)["header"]) as fh:
+        text = fh.read()
+    names = {host.ALG_ID: "ID", host.ALG_MINV: "MINV", host.ALG_FD: "FD", host.ALG_ID_DU: "ID_DU", host.ALG_FD_DU: "FD_DU"}
+    limit = {a: int(re.search(r"const int %s_WAVE_AUTO_MAX_K = (\d+);" % nm, text).group(1)) for a, nm in names.items()}
+    T = tables(robot)
+    with host.GridHandle(robot, device=0, precision=host.DEFAULT_PRECISION) as h:
+        n = h.n
+        for a, lim in limit.items():
+            assert h.wave_available(a)
+            if lim == 0:
+                assert not h.get_wave(a, 1) and not h.get_wave(a, 64)
+            else:
+                assert h.get_wave(a, 1) and h.get_wave(a, lim) and not h.get_wave(a, lim + 1)
+        assert limit[host.ALG_FD_DU] == (1024 if n > 12 else 0)
+        h.set_split(host.ALG_FD_DU, 1)                               # an explicit choice of another variant wins
+        assert not h.get_wave(host.ALG_FD_DU, 64)
+        h.set_split(host.ALG_FD_DU, 0)
+        K = max(limit[host.ALG_FD], limit[host.ALG_FD_DU], 64)
+        q, qd, u = make_inputs(n, K, 77)
+        ref = oracle_all(T, q, qd, u)
+        d_in = torch.from_numpy(pack(q, qd, u)).cuda()
+        qdd = torch.full((K, n), 9.5, dtype=torch.float32, device="cuda")
+        df = torch.full((K, 2 * n * n), 9.5, dtype=torch.float32, device="cuda")
+        h.forward_dynamics_device(qdd.data_ptr(), d_in.data_ptr(), 3 * n, K)
+        h.forward_dynamics_gradient_device(df.data_ptr(), d_in.data_ptr(), 3 * n, K)
+        h.synchronize()
+        assert relerr(qdd.cpu().numpy(), ref["qdd"])[0] < TOL[robot]["qdd"]
+        assert relerr(df.cpu().numpy(), ref["df_du"])[0] < TOL[robot]["df_du"]
