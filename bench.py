@@ -17,7 +17,11 @@ Sharding: the batch dimension is embarrassingly parallel, every rank owns its ow
 barrier and the max-over-ranks of the elapsed time.
 
 roofline: algorithmic bytes per launch = 4*(3n + 2n^2) * batch, divided by the
-kernel's average launch duration measured with HIP events on the launch stream (grid_time_device).  ``kernel`` is the
+kernel's average launch duration.  Three clocks see a launch in this run -- HIP events recorded on the launch stream around the timed
+region itself, HIP events around a further set of back-to-back launches (grid_time_device), and the host's wall clock per step --
+and ``roofline.achieved`` / ``frac`` are priced on the SLOWEST of them; ``roofline.clock`` names it, ``clocks_us`` lists all three.
+``secondary`` holds the other single-GPU configurations of BASELINE.json (C2, C3's forward dynamics, C4) and north_star's Atlas-30
+batch-16k target, each with its own ``roofline``.  ``kernel`` is the
 kernel the C ABI actually dispatched (e.g. ``..._kernel_split4``) with that kernel's registers.  ``traffic`` comes from
 the committed rocprofv3 PMC passes (profiles/pmc_traffic.json) and is printed only when that entry was measured on the
 same generated header (sha recorded with the entry) -- otherwise null.
@@ -153,8 +157,13 @@ def launch_ranks(n_gpus, argv):
     rehearsal (every rank on device 0, gloo).  GRID_BENCH_DRY_RUN=1 prints the command instead of running it (tests)."""
     import socket
     import subprocess
-    import torch                                   # (device_count() does not initialise the GPU runtime)
-    have = torch.cuda.device_count()
+    from gridcodegenerator_amd import sharding
+    # counted from sysfs (KFD topology + *_VISIBLE_DEVICES): this process must never initialise HIP/HSA -- the ranks are its children
+    # (torch.cuda.device_count() can fall back to hipGetDeviceCount, which does).  No readable topology: let the ranks find out.
+    have = sharding.visible_gpu_count()
+    if have is None:        # no KFD topology in sysfs: without /dev/kfd there is no ROCm GPU; with it, one per render node
+        import glob
+        have = len(glob.glob("/dev/dri/renderD*")) if os.path.exists("/dev/kfd") else 0
     rehearsal = os.environ.get("GRID_BENCH_REHEARSAL") == "1"
     if have < n_gpus and not rehearsal:
         print("bench.py: --gpus %d requested but %d GPU(s) are visible; refusing to report a %d-GPU number from fewer devices "
@@ -175,14 +184,15 @@ def launch_ranks(n_gpus, argv):
 class Workload:
     """One robot / batch on this rank's GPU: device-resident inputs and outputs, one handle, the launch closure."""
 
-    def __init__(self, torch, host, robot, K, precision, device, seed, blocks=0, threads=0, split=0, coop=0, streams=1, wave=0):
+    def __init__(self, torch, host, robot, K, precision, device, seed, blocks=0, threads=0, split=0, coop=0, streams=1, wave=0, alg=None):
         host.build_library(robot, precision)
         self.host, self.torch, self.robot, self.K, self.precision = host, torch, robot, K, precision
+        self.alg = host.ALG_FD_DU if alg is None else alg
         self.h = host.GridHandle(robot, device=device, precision=precision)
         self.n = n = self.h.n
         q, qd, u = make_inputs(n, K, seed)
         self.d_in = torch.from_numpy(np.ascontiguousarray(np.concatenate([q, qd, u], axis=1))).cuda()
-        self.d_out = torch.empty((K, 2 * n * n), dtype=torch.float32, device="cuda")
+        self.d_out = torch.empty((K, host.output_size(self.alg, n)), dtype=torch.float32, device="cuda")
         # torch's current stream (0 = the default stream: GridHandle passes it on as hipStreamLegacy; a NULL pointer would mean the
         # handle's own non-blocking stream to the C ABI, which is not ordered with torch's work)
         self.stream = torch.cuda.current_stream().cuda_stream
@@ -195,21 +205,36 @@ class Workload:
         self.outs = [self.d_out] + [torch.empty_like(self.d_out) for _ in range(self.n_streams - 1)]
         self.step_no = 0
         self.blocks, self.threads = blocks, threads
-        self.h.set_split(host.ALG_FD_DU, split)
+        self.h.set_split(self.alg, split)
         if coop:
-            self.h.set_coop(host.ALG_FD_DU, coop)
+            self.h.set_coop(self.alg, coop)
         if wave:
-            self.h.set_wave(host.ALG_FD_DU, wave)
-        # precedence in the C ABI: wave-per-configuration kernel (small batches of large robots), tile-cooperative kernel, column split
-        self.wave_used = self.h.get_wave(host.ALG_FD_DU, K)
-        self.coop_used = (not self.wave_used) and self.h.get_coop(host.ALG_FD_DU, K)
-        self.split_used = 1 if (self.coop_used or self.wave_used) else self.h.get_split(host.ALG_FD_DU, K)
+            self.h.set_wave(self.alg, wave)
+        # precedence in the C ABI: wave-per-configuration kernel (small batches), tile-cooperative kernel, column split; an explicit
+        # launch shape keeps the lane-per-configuration kernels (include/grid_capi.h)
+        self.wave_used = self.h.get_wave(self.alg, K) and not (blocks or threads)
+        self.coop_used = (not self.wave_used) and self.h.get_coop(self.alg, K)
+        self.split_used = 1 if (self.coop_used or self.wave_used) else self.h.get_split(self.alg, K)
+
+    def launch(self, d_out_ptr, stream):
+        """One pass of the algorithm over the batch through the C ABI (device pointers: the reference's _compute_only mode)."""
+        host, h, n = self.host, self.h, self.n
+        kw = dict(blocks=self.blocks, threads=self.threads, stream=stream)
+        if self.alg == host.ALG_FD_DU:
+            h.forward_dynamics_gradient_device(d_out_ptr, self.d_in.data_ptr(), 3 * n, self.K, gravity=GRAVITY, **kw)
+        elif self.alg == host.ALG_ID_DU:
+            h.inverse_dynamics_gradient_device(d_out_ptr, self.d_in.data_ptr(), 3 * n, self.K, gravity=GRAVITY, **kw)
+        elif self.alg == host.ALG_FD:
+            h.forward_dynamics_device(d_out_ptr, self.d_in.data_ptr(), 3 * n, self.K, gravity=GRAVITY, **kw)
+        elif self.alg == host.ALG_MINV:
+            h.direct_minv_device(d_out_ptr, self.d_in.data_ptr(), 3 * n, self.K, **kw)
+        else:
+            h.inverse_dynamics_device(d_out_ptr, self.d_in.data_ptr(), 3 * n, self.K, gravity=GRAVITY, **kw)
 
     def step(self):
         i = self.step_no % self.n_streams
         self.step_no += 1
-        self.h.forward_dynamics_gradient_device(self.outs[i].data_ptr(), self.d_in.data_ptr(), 3 * self.n, self.K, gravity=GRAVITY,
-                                                blocks=self.blocks, threads=self.threads, stream=self.stream_ptrs[i])
+        self.launch(self.outs[i].data_ptr(), self.stream_ptrs[i])
 
     def prewarm(self, seconds):
         # Bring the GPU out of its idle power state (the default run is only a few ms of kernels).  Not warm-up, not steps.
@@ -221,24 +246,36 @@ class Workload:
 
     def measure(self, sharding, dist, steps, warmup, world, reduce_device):
         host, torch = self.host, self.torch
-        elapsed = sharding.timed_steps(self.step, steps, warmup, torch.cuda.synchronize, dist, reduce_device=reduce_device)
+        # HIP events on the launch stream around the timed region itself (torch events are recorded on torch's current stream, which
+        # IS the launch stream here: main() makes a stream of its own current and Workload.stream is that stream)
+        ev = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)] if self.n_streams == 1 else None
+        elapsed = sharding.timed_steps(self.step, steps, warmup, torch.cuda.synchronize, dist, reduce_device=reduce_device,
+                                       on_start=(lambda: ev[0].record()) if ev else None, on_stop=(lambda: ev[1].record()) if ev else None)
+        region_ms = (ev[0].elapsed_time(ev[1]) / steps) if ev else None
         reps = max(20, min(steps, 200)) if self.K <= 65536 else max(5, min(steps, 20))
-        kern_ms = self.h.time_device(host.ALG_FD_DU, self.d_out.data_ptr(), self.d_in.data_ptr(), 3 * self.n, self.K, gravity=GRAVITY,
-                                     blocks=self.blocks, threads=self.threads, stream=self.stream, reps=reps)
+        b2b_ms = self.h.time_device(self.alg, self.d_out.data_ptr(), self.d_in.data_ptr(), 3 * self.n, self.K, gravity=GRAVITY,
+                                    blocks=self.blocks, threads=self.threads, stream=self.stream, reps=reps)
         finite = bool(torch.isfinite(self.d_out).all().item())
         n, K = self.n, self.K
-        kernel = "forward_dynamics_gradient_kernel" + ("_wave" if self.wave_used else "_coop" if self.coop_used else
-                                                       ("_split%d" % self.split_used if self.split_used > 1 else ""))
-        attrs = self.h.L.kernel_attributes(host.ALG_FD_DU, split=self.split_used, coop=self.coop_used, wave=self.wave_used)
+        kernel = host.ALG_NAMES[self.alg] + "_kernel" + ("_wave" if self.wave_used else "_coop" if self.coop_used else
+                                                          ("_split%d" % self.split_used if self.split_used > 1 else ""))
+        attrs = self.h.L.kernel_attributes(self.alg, split=self.split_used, coop=self.coop_used, wave=self.wave_used)
         sha = header_sha(self.robot, self.precision)
         traffic, traffic_round = committed_traffic(self.robot, K, kernel, sha)
-        alg_bytes = host.algorithmic_bytes(host.ALG_FD_DU, n) * K
+        alg_bytes = host.algorithmic_bytes(self.alg, n) * K
+        # roofline.achieved is priced on the SLOWEST of the clocks this run has for one launch, and says which: HIP events around the
+        # timed region, HIP events around `reps` more back-to-back launches (grid_time_device), the host's wall clock per step
+        clocks = {"hip_events_back_to_back": b2b_ms, "wall_per_step": 1e3 * elapsed / steps}
+        if region_ms is not None:
+            clocks["hip_events_timed_region"] = region_ms
+        clock = max(clocks, key=lambda c: clocks[c]) if self.n_streams == 1 else "hip_events_back_to_back"
+        kern_ms = clocks[clock]
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         return {
             "value": sharding.aggregate_throughput(K, world, steps, elapsed), "unit": "evals/s", "steps": steps, "warmup": warmup,
             "ms_per_step": 1e3 * elapsed / steps, "dtype": self.h.L.compute_dtype,
-            "config": {"workload": "%s forward_dynamics_gradient_kernel, batch %d per GPU, fp32 I/O, device-resident (reference _compute_only)"
-                                   % (self.robot, K),
+            "config": {"workload": "%s %s_kernel, batch %d per GPU, fp32 I/O, device-resident (reference _compute_only)"
+                                   % (self.robot, host.ALG_NAMES[self.alg], K),
                        "robot": self.robot, "num_joints": n, "batch_per_gpu": K, "global_batch": K * world,
                        "parallelism": "batch-sharded x%d, independent streams, no collective on the data path%s"
                                       % (world, "" if self.n_streams == 1 else "; steps round-robin over %d streams per GPU" % self.n_streams),
@@ -252,10 +289,11 @@ class Workload:
                          "traffic": traffic,
                          "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE passes of %s on this header; null = not measured on this header)"
                                          % (traffic_round or "profiles/"),
-                         "kernel": kernel, "kernel_avg_us": 1e3 * kern_ms,
+                         "kernel": kernel, "kernel_avg_us": 1e3 * kern_ms, "clock": clock,
+                         "clocks_us": {c: 1e3 * v for c, v in clocks.items()},
                          "traffic_GBps": (traffic / (kern_ms * 1e-3) / 1e9) if traffic else None,
                          "traffic_frac": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
-                         "algorithmic_bytes_per_eval": host.algorithmic_bytes(host.ALG_FD_DU, n),
+                         "algorithmic_bytes_per_eval": host.algorithmic_bytes(self.alg, n),
                          "kernel_evals_per_s": K / (kern_ms * 1e-3)},
         }
 
@@ -373,12 +411,21 @@ def main():
         w1.close()
         # ... Atlas-30 at batch 16k, and its small-batch path (64 configurations, dispatched to the
         # wave-per-configuration kernel -- `ms_per_step` is the latency of one dependent launch)
-        plan = [("atlas30_batch16384", "atlas30", 16384, min(args.steps, 50), min(args.warmup, 5)),
-                ("atlas30_batch64_small_batch_path", "atlas30", 64, min(args.steps, 50), min(args.warmup, 5))]
+        FD_DU, ID_DU, ID, FD = host.ALG_FD_DU, host.ALG_ID_DU, host.ALG_ID, host.ALG_FD
+        plan = [("atlas30_batch16384", "atlas30", 16384, min(args.steps, 50), min(args.warmup, 5), FD_DU),
+                ("atlas30_batch64_small_batch_path", "atlas30", 64, min(args.steps, 50), min(args.warmup, 5), FD_DU)]
+        if world == 1:
+            # the other single-GPU configurations of BASELINE.json, each with its own roofline: C2 (iiwa-7 RNEA + its gradient, batch
+            # 1024), C3's forward dynamics (its gradient is the headline), C4 (Atlas-30 ID and FD gradients, batch 65536)
+            plan += [("C2_iiwa7_batch1024_inverse_dynamics", "iiwa7", 1024, min(args.steps, 50), min(args.warmup, 5), ID),
+                     ("C2_iiwa7_batch1024_inverse_dynamics_gradient", "iiwa7", 1024, min(args.steps, 50), min(args.warmup, 5), ID_DU),
+                     ("C3_iiwa7_batch16384_forward_dynamics", "iiwa7", 16384, min(args.steps, 50), min(args.warmup, 5), FD),
+                     ("C4_atlas30_batch65536_forward_dynamics_gradient", "atlas30", 65536, min(args.steps, 25), min(args.warmup, 3), FD_DU),
+                     ("C4_atlas30_batch65536_inverse_dynamics_gradient", "atlas30", 65536, min(args.steps, 25), min(args.warmup, 3), ID_DU)]
         if world > 1:
-            plan.append(("atlas30_batch131072_per_gpu", "atlas30", 131072, min(args.steps, 10), min(args.warmup, 2)))
-        for (key, robot, K, steps, warmup) in plan:
-            w2 = Workload(torch, host, robot, K, args.precision, local_rank, 5 + rank)
+            plan.append(("atlas30_batch131072_per_gpu", "atlas30", 131072, min(args.steps, 10), min(args.warmup, 2), FD_DU))
+        for (key, robot, K, steps, warmup, alg) in plan:
+            w2 = Workload(torch, host, robot, K, args.precision, local_rank, 5 + rank, alg=alg)
             w2.prewarm(min(args.prewarm_s, 0.2))
             line = w2.measure(sharding, dist, steps, warmup, world, reduce_device)
             w2.close()

@@ -267,11 +267,17 @@ static int wave_auto_max_k(int alg) {
     }
 }
 static bool wave_available(int alg) { return alg >= 0 && alg <= 4 && G::FD_DU_WAVE_WAVES > 0; }
-static bool use_wave(const grid_handle *h, int alg, int K, const float *d_qdd, const float *d_Minv) {
+static bool use_wave(const grid_handle *h, int alg, int K, const float *d_qdd, const float *d_Minv, int blocks = 0, int threads = 0) {
     if (!wave_available(alg) || d_Minv != nullptr || h->wave[alg] == 1) return false;
     if (alg == GRID_ALG_FD_DU && d_qdd != nullptr) return false;       // (precomputed qdd/Minv: the lane-per-configuration kernel)
     if (h->wave[alg] == 2) return true;
     if (h->split[alg] != 0 || h->pipeline[alg] == 2 || h->coop[alg] == 2) return false;
+    // A caller that passes a launch shape means blocks of `threads` CONFIGURATIONS (the reference's <<<block_dimms, thread_dimms>>>,
+    // lane-per-configuration here); in the wave-per-configuration kernels a block IS one configuration, so the same numbers would mean
+    // blocks*1 configurations in flight, each block walking K/blocks of them serially.  The automatic choice therefore keeps to the
+    // launch shape's meaning: an explicit shape gets the lane-per-configuration kernels (grid_set_wave(..., 2) takes `blocks` as the
+    // number of configurations in flight on purpose).
+    if (blocks > 0 || threads > 0) return false;
     return wave_auto_max_k(alg) > 0 && K <= wave_auto_max_k(alg);
 }
 
@@ -301,8 +307,8 @@ static int launch_alg(grid_handle *h, int alg, float *d_out, const float *d_in, 
                       int K, float gravity, int blocks, int threads, hipStream_t s) {
     dim3 b, t;
     launch_shape(K, blocks, threads, &b, &t);
-    if (use_wave(h, alg, K, d_qdd, d_Minv)) {
-        const int nb = blocks > 0 ? blocks : 0;
+    if (use_wave(h, alg, K, d_qdd, d_Minv, blocks, threads)) {
+        const int nb = blocks > 0 ? blocks : 0;       // (reached with an explicit shape only under grid_set_wave(..., 2): configurations in flight)
         switch (alg) {
         case GRID_ALG_ID:    G::inverse_dynamics_wave_launch<T>(d_out, d_in, stride, d_qdd, h->d_robotModel, gravity, K, nb, s); break;
         case GRID_ALG_MINV:  G::direct_minv_wave_launch<T>(d_out, d_in, stride, h->d_robotModel, K, nb, s); break;
@@ -313,7 +319,11 @@ static int launch_alg(grid_handle *h, int alg, float *d_out, const float *d_in, 
         return grid_check("kernel launch (wave-per-configuration)");
     }
     if (use_coop(h, alg, K, d_qdd, d_Minv)) {
-        G::forward_dynamics_gradient_coop_launch<T>(d_out, d_in, stride, h->d_robotModel, gravity, K, blocks > 0 ? blocks : 0, s);
+        // an explicit launch shape means blocks x threads configurations in flight: that many tiles of 64 (one block of the kernel each)
+        int tile_blocks = 0;
+        if (blocks > 0) { const long long cfgs = (long long)blocks * (threads > 0 ? threads : G::GRID_WAVE_SIZE);
+                          tile_blocks = (int)((cfgs + G::GRID_WAVE_SIZE - 1) / G::GRID_WAVE_SIZE); }
+        G::forward_dynamics_gradient_coop_launch<T>(d_out, d_in, stride, h->d_robotModel, gravity, K, tile_blocks, s);
         return grid_check("kernel launch (tile-cooperative)");
     }
     if (use_pipeline(h, alg, d_qdd, d_Minv)) {

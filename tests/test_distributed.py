@@ -109,3 +109,59 @@ def test_bench_gpus_n_without_a_launcher_cannot_report_one_gpu():
 def test_bench_rejects_a_world_size_that_contradicts_gpus():
     run = _bench(["--gpus", "2", "--steps", "3"], WORLD_SIZE="4", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
     assert run.returncode != 0 and "does not match WORLD_SIZE" in (run.stderr + run.stdout)
+
+
+def test_visible_gpu_count_reads_sysfs_and_visibility_masks(tmp_path, monkeypatch):
+    """The launcher counts GPUs from the KFD topology (nodes with SIMDs; CPU nodes have simd_count 0) cut down by the *_VISIBLE_DEVICES
+    variables -- no HIP call.  Fake topology: one CPU node, three GPU nodes, one unreadable node."""
+    root = tmp_path / "nodes"
+    for i, simd in enumerate([0, 1024, 1024, 1024]):
+        d = root / str(i); d.mkdir(parents=True)
+        (d / "properties").write_text("cpu_cores_count %d\nsimd_count %d\nmem_banks_count 1\n" % (64 if simd == 0 else 0, simd))
+    (root / "4").mkdir()                                   # no properties file (another cgroup's device)
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert sharding.visible_gpu_count(str(root)) == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert sharding.visible_gpu_count(str(root)) == 2
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "1")
+    assert sharding.visible_gpu_count(str(root)) == 1
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "")
+    assert sharding.visible_gpu_count(str(root)) == 0
+    assert sharding.visible_gpu_count(str(tmp_path / "absent")) is None
+
+
+def test_the_launcher_never_touches_torch_cuda():
+    """bench.launch_ranks() runs in the process that becomes the parent of the ranks: it must not initialise (or even import) the GPU
+    side of torch -- checked in a fresh interpreter with the dry-run switch."""
+    code = ("import os, sys; sys.argv = ['bench.py']; sys.path.insert(0, %r); os.environ['GRID_BENCH_REHEARSAL'] = '1'; "
+            "os.environ['GRID_BENCH_DRY_RUN'] = '1'; import bench; rc = bench.launch_ranks(2, ['--gpus', '2']); "
+            "assert rc == 0; assert 'torch' not in sys.modules, 'the launcher imported torch'; print('clean')" % REPO)
+    run = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert run.returncode == 0 and run.stdout.strip().endswith("clean"), run.stderr
+
+
+def test_in_process_shards_on_host_threads():
+    """run_shards_in_process: one host thread per device, contiguous slices, the elapsed time is the slowest thread's, every shard's
+    steps are counted, and a failing shard's exception reaches the caller (CPU stand-ins for the per-device handles)."""
+    import time
+    log = []
+
+    def make_shard(index, device, lo, hi):
+        calls = []
+        log.append((index, device, lo, hi, calls))
+        return (lambda: (calls.append(1), time.sleep(0.01 * (index + 1)))), (lambda: None)
+    res = sharding.run_shards_in_process(1000, ["gpu0", "gpu1", "gpu2"], make_shard, steps=4, warmup=2)
+    log.sort()
+    assert [(i, d, lo, hi) for (i, d, lo, hi, _) in log] == [(0, "gpu0", 0, 333), (1, "gpu1", 333, 666), (2, "gpu2", 666, 1000)]
+    assert all(len(calls) == 6 for (*_, calls) in log)
+    assert res["elapsed"] >= 4 * 0.03 * 0.9 and res["elapsed"] == max(t for (_, _, t) in res["per_shard"])
+    assert abs(res["value"] - 1000 * 4 / res["elapsed"]) < 1e-6
+
+    def bad(index, device, lo, hi):
+        if index == 1:
+            raise RuntimeError("shard 1 failed")
+        return (lambda: None), (lambda: None)
+    import pytest
+    with pytest.raises(RuntimeError, match="shard 1 failed"):
+        sharding.run_shards_in_process(10, [0, 1], bad, steps=1)

@@ -567,6 +567,40 @@ def test_two_handles_in_one_process(handles, tables, torch_cuda):
     assert np.array_equal(got, whole.cpu().numpy())
 
 
+def test_in_process_shards_without_a_launcher(handles, tables, torch_cuda):
+    """sharding.run_shards_in_process: one host thread, one handle and one stream per device entry (here device 0 three times -- the
+    box has one GPU), no launcher, no collective; the concatenated shards equal the un-sharded evaluation bit for bit."""
+    torch = torch_cuda
+    from gridcodegenerator_amd import host, sharding
+    n, K = 7, 5000
+    q, qd, u = make_inputs(n, K, 78)
+    d_x = torch.from_numpy(pack(q, qd, u)).cuda()
+    whole = torch.empty((K, 2 * n * n), dtype=torch.float32, device="cuda")
+    h0 = handles("iiwa7")
+    torch.cuda.synchronize()
+    h0.forward_dynamics_gradient_device(whole.data_ptr(), d_x.data_ptr(), 3 * n, K)
+    h0.synchronize()
+    outs, made = {}, []
+
+    def make_shard(index, device, lo, hi):
+        torch.cuda.set_device(device)
+        h = host.GridHandle("iiwa7", device=device, precision=host.DEFAULT_PRECISION)
+        st = h.own_stream(0)
+        out = torch.empty((hi - lo, 2 * n * n), dtype=torch.float32, device="cuda:%d" % device)
+        outs[index] = out
+        made.append(h)
+        step = lambda: h.forward_dynamics_gradient_device(out.data_ptr(), d_x.data_ptr() + 4 * 3 * n * lo, 3 * n, hi - lo, stream=st)
+        return step, (lambda: h.synchronize(stream=st))
+    try:
+        res = sharding.run_shards_in_process(K, [0, 0, 0], make_shard, steps=5, warmup=1)
+        got = torch.cat([outs[i] for i in range(3)]).cpu().numpy()
+    finally:
+        for h in made:
+            h.close()
+    assert np.array_equal(got, whole.cpu().numpy())
+    assert res["value"] > 0 and len(res["per_shard"]) == 3 and res["per_shard"][1][:2] == sharding.shard_bounds(K, 3, 1)
+
+
 def test_null_stream_is_caller_ordered(handles, torch_cuda):
     """C ABI: stream == NULL is the default stream, ordered with the torch work that produced the buffers.  Every launch below
     follows a NaN fill of its large output buffer with NO synchronisation in between; with NULL meaning a non-blocking stream of

@@ -289,6 +289,25 @@ def test_automatic_choice_follows_the_header_thresholds(robot, tables):
         h.set_split(host.ALG_FD_DU, 1)                               # an explicit choice of another variant wins
         assert not h.get_wave(host.ALG_FD_DU, 64)
         h.set_split(host.ALG_FD_DU, 0)
+        if limit[host.ALG_FD] > 0:
+            # ... and so does an explicit launch shape: blocks x threads means blocks of `threads` CONFIGURATIONS (the reference's
+            # <<<block_dimms, thread_dimms>>>), which only the lane-per-configuration kernels honour -- the automatic choice must not
+            # turn 4 blocks of 64 threads into 4 configurations in flight.  Bitwise: automatic + shape == wave kernels off + shape,
+            # automatic without a shape == wave kernel forced.
+            Kx = min(limit[host.ALG_FD], 256)
+            q, qd, u = make_inputs(n, Kx, 78)
+            d_in = torch.from_numpy(pack(q, qd, u)).cuda()
+            res = {}
+            for name, mode, kw in (("auto_shape", 0, dict(blocks=4, threads=64)), ("never_shape", 1, dict(blocks=4, threads=64)),
+                                   ("auto", 0, {}), ("always", 2, {})):
+                h.set_wave(host.ALG_FD, mode)
+                o = torch.full((Kx, n), 9.5, dtype=torch.float32, device="cuda")
+                h.forward_dynamics_device(o.data_ptr(), d_in.data_ptr(), 3 * n, Kx, **kw)
+                h.synchronize()
+                res[name] = o.cpu().numpy()
+            h.set_wave(host.ALG_FD, 0)
+            assert np.array_equal(res["auto_shape"], res["never_shape"]) and np.array_equal(res["auto"], res["always"])
+            assert not np.array_equal(res["auto"], res["never_shape"])          # (different kernels round differently)
         K = max(limit[host.ALG_FD], limit[host.ALG_FD_DU], 64)
         q, qd, u = make_inputs(n, K, 77)
         ref = oracle_all(T, q, qd, u)
