@@ -249,6 +249,8 @@ class Workload:
         # HIP events on the launch stream around the timed region itself (torch events are recorded on torch's current stream, which
         # IS the launch stream here: main() makes a stream of its own current and Workload.stream is that stream)
         ev = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)] if self.n_streams == 1 else None
+        if ev:      # (a torch event is created lazily by its first record(): ~30 us of host time that would sit INSIDE a 200 us timed region)
+            ev[0].record(); ev[1].record(); torch.cuda.synchronize()
         elapsed = sharding.timed_steps(self.step, steps, warmup, torch.cuda.synchronize, dist, reduce_device=reduce_device,
                                        on_start=(lambda: ev[0].record()) if ev else None, on_stop=(lambda: ev[1].record()) if ev else None)
         region_ms = (ev[0].elapsed_time(ev[1]) / steps) if ev else None
@@ -257,7 +259,7 @@ class Workload:
                                     blocks=self.blocks, threads=self.threads, stream=self.stream, reps=reps)
         finite = bool(torch.isfinite(self.d_out).all().item())
         n, K = self.n, self.K
-        kernel = host.ALG_NAMES[self.alg] + "_kernel" + ("_wave" if self.wave_used else "_coop" if self.coop_used else
+        kernel = host.ALG_NAMES[self.alg] + "_kernel" + ("_wave" if self.wave_used else "_coop8" if self.coop_used == 2 else "_coop" if self.coop_used else
                                                           ("_split%d" % self.split_used if self.split_used > 1 else ""))
         attrs = self.h.L.kernel_attributes(self.alg, split=self.split_used, coop=self.coop_used, wave=self.wave_used)
         sha = header_sha(self.robot, self.precision)
@@ -280,7 +282,7 @@ class Workload:
                        "parallelism": "batch-sharded x%d, independent streams, no collective on the data path%s"
                                       % (world, "" if self.n_streams == 1 else "; steps round-robin over %d streams per GPU" % self.n_streams),
                        "launch": {"blocks": self.blocks or "suggested", "threads": self.threads or self.h.L.constants["SUGGESTED_THREADS"],
-                                  "column_split": self.split_used, "tile_cooperative": bool(self.coop_used),
+                                  "column_split": self.split_used, "tile_cooperative": {0: False, 1: "4 waves per tile", 2: "8 waves per tile (register-lean)"}[int(self.coop_used)],
                                   "wave_per_configuration": bool(self.wave_used)},
                        "kernel": {"name": kernel, "vgprs": attrs["numRegs"], "scratch_bytes_per_lane": attrs["scratch_bytes_per_lane"],
                                   "header_sha": sha},
@@ -355,7 +357,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--split", type=int, default=0, help="column-split factor of the gradient kernel: 0 auto, 1 never, S force")
-    ap.add_argument("--coop", type=int, default=0, help="tile-cooperative gradient kernel: 0 auto, 1 never, 2 always")
+    ap.add_argument("--coop", type=int, default=0, help="tile-cooperative gradient kernel: 0 auto, 1 never, 2 always (4 waves), 3 always the register-lean 8-wave variant")
     ap.add_argument("--all-kernels", action="store_true", help="also time the other four kernels (reported under 'kernels')")
     args = ap.parse_args()
 

@@ -24,6 +24,9 @@ Generation-time knobs that have no reference counterpart are keyword-only:
                      ("fused" with n > 12 spills kilobytes per lane; correct since the kernels are branch-free)
     grad_splits      "auto" | list    column-split variants of the two gradient kernels to emit (small-batch speed)
     waves_per_simd                    __launch_bounds__ occupancy hint for the unsplit kernels (caps registers at 512/w)
+    prismatic_gradient "corrected" | "reference"   the d/dq seed of a prismatic joint's own column: force cross product (agrees with
+                                      finite differences; default) or the reference's motion cross product (_test.py:311,437) so that
+                                      such a robot's gradients can be compared with the reference's numbers; identical for revolute joints
     allow_unverified bool             accept what reintroduces lane-divergent control flow (trig="libm"/"f64", out_mode="direct"):
                                       such kernels are unverified on the GPU
     experimental     dict             measured-and-rejected or test-only variants, NOT part of the supported surface
@@ -35,6 +38,10 @@ from .helpers._runtime_emit import RuntimeEmitMixin
 from .helpers._spatial_emit import SpatialAlgebraEmitMixin
 from .helpers._text import TextMixin
 from .verification import VerificationMixin
+
+
+class GridGenerationWarning(UserWarning):
+    """A kernel family was left out, or a kernel is predicted to exceed the register file, for this robot (see `generation_notes`)."""
 
 
 class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, SpatialAlgebraEmitMixin, AlgorithmEmitMixin, VerificationMixin):
@@ -61,6 +68,17 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, SpatialAlgebraEmitMixin, Al
         split_half_columns=True,  # ... and the sets may hold HALF columns (d/dq and d/dqd of a column in different groups) where that
                                 # lowers the heaviest group: iiwa-7 dFD x4 2937 -> 2771 operations, dID x4 1658 -> 1507
         in_rows=False,          # inputs by per-lane 16-byte row loads instead of coalesced loads staged through LDS (grid_rows)
+        split_flush_slots=10,   # half-column sets of the S >= 3 splits balanced on arithmetic + this many issue slots per OUTPUT value (the stamped
+                                # 4-way kernel: ~43 cycles = ~10 slots per value).  iiwa-7 dFD K = 16384: 9.32-9.52 us (0) -> 8.83-8.96 (10), 9.09 (20)
+                                # -- profiles/r04/exp_iiwa7_asymmetric_pairs.txt
+        split_asym=0,           # > 0: also emit the ASYMMETRIC 8-way split (4 heavy groups on the waves dispatched first, 4 light ones whose
+                                # cost counts this many times) as `*_kernel_split8`, one 512-thread block per tile.  Measured 9.31-9.37 us at
+                                # 1.4-2.5 against 8.83-8.96 for the flush-balanced 4-way split: rejected (same file)
+        wave_occupancy=1,       # wave-per-configuration kernels: waves per SIMD the register allocation must leave room for (2: <= 256 registers)
+        lean_read_ahead=0,      # register-lean 8-wave kernel: LDS reads issued this many instructions ahead of their use (Tracer.emit read_ahead)
+        lean_plan={},           # register-lean 8-wave kernel: keyword overrides of cores.lean_plan (younger_speed, max_parked)
+        lean_probe=None,        # register-lean 8-wave kernel, timing probes (NOT a correct kernel): "prefix" = phases 0-2 only, "older" / "younger" =
+                                # only the waves dispatched first / last keep their gradient half-columns (profiles/r04/lean_probes.txt)
         coop_hoist=False,       # tile-cooperative cores of small robots: force everything that does not depend on qdd in front of
                                 # the first barrier (and let the producer go without columns): 12.9 vs 12.1 us at K=16384
     )
@@ -68,7 +86,7 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, SpatialAlgebraEmitMixin, Al
     def __init__(self, robotObj, DEBUG_MODE=False, NEED_PRINT_MAT=False, USE_DYNAMIC_SHARED_MEM=True,
                  FILE_NAMESPACE="grid", *, precision="fp32", trig="fast", suggested_threads=64, max_threads=256,
                  suggested_max_blocks=2048, out_chunk=64, emit_inner_api=True, pipeline="auto", grad_schedule="auto",
-                 grad_splits="auto", waves_per_simd=1, allow_unverified=False, experimental=None):
+                 grad_splits="auto", waves_per_simd=1, allow_unverified=False, experimental=None, prismatic_gradient="corrected"):
         if precision not in ("fp32", "mixed", "fp64"):
             raise ValueError("precision must be 'fp32', 'mixed' or 'fp64'")
         if trig not in ("fast", "libm", "f64"):
@@ -77,6 +95,10 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, SpatialAlgebraEmitMixin, Al
             raise ValueError("need 64 <= suggested_threads <= max_threads <= 1024, suggested_threads a multiple of 64")
         if grad_schedule not in ("auto", "fused", "recompute"):
             raise ValueError("grad_schedule must be 'auto', 'fused' or 'recompute'")
+        if prismatic_gradient not in ("corrected", "reference"):
+            raise ValueError("prismatic_gradient must be 'corrected' (force cross product: agrees with finite differences) or 'reference' "
+                             "(the reference's motion cross product, _test.py:311,437: identical for revolute joints)")
+        self.prismatic_gradient = prismatic_gradient
         exp = dict(self.EXPERIMENTAL_DEFAULTS)
         unknown = set(experimental or {}) - set(exp)
         if unknown:
@@ -128,8 +150,16 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, SpatialAlgebraEmitMixin, Al
         self.dot_ways = int(exp["dot_ways"])
         self.split_cap = tuple(int(x) for x in exp["split_cap"])
         self.coop_hoist = bool(exp["coop_hoist"])
+        self.lean_probe = exp["lean_probe"]
+        self.wave_occupancy = int(exp["wave_occupancy"])
+        self.split_flush_slots = float(exp["split_flush_slots"])
+        self.split_asym = float(exp["split_asym"])
+        self.lean_plan_options = dict(exp["lean_plan"])
+        self.lean_read_ahead = int(exp["lean_read_ahead"])
         self.in_rows = bool(exp["in_rows"])
         self.split_half_columns = bool(exp["split_half_columns"])
+        self.lean_auto_min_tiles = 1       # register-lean 8-wave kernel: automatic from this many tiles on (0: on request) -- measured faster than
+                                           # the 4-wave kernel at every batch size (profiles/r04/lean_sweep.txt)
         self.wave_auto_max_k = 1024        # batch sizes up to which large robots use the wave-per-configuration kernel by themselves
         # ... for the other algorithms, by robot size: measured on MI355X with tools/latency_all.py (profiles/r03/latency_all_*.txt), us per
         # launch lane-per-configuration / wave-per-configuration.  Atlas-30: ID 9.9 / 6.6 at K = 1024 (9.9 / 13.9 at 2048), MINV 32.4 / 27.8
@@ -139,6 +169,8 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, SpatialAlgebraEmitMixin, Al
                                 {"ID": 512, "MINV": 1024, "FD": 512, "ID_DU": 0} if self.spec.n >= 7 else {"ID": 0, "MINV": 0, "FD": 0, "ID_DU": 0})
         self.kernel_instances = []
         self.split_stats = {}
+        self.generation_notes = []          # what was left out / is predicted to spill for this robot (GridGenerationWarning)
+        self.predicted_live = {}
         self.emit_inner_api = bool(emit_inner_api)
         self.core_stats = {}
         self.trace_stats = {}
@@ -169,6 +201,28 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, SpatialAlgebraEmitMixin, Al
         self.gen_add_code_line("#define GRID_FOR_EACH_KERNEL_INST(KW) " + " ".join("GRID_KERNEL_INST_%d(KW)" % k
                                                                                    for k in range(len(self.kernel_instances))))
 
+    def note(self, text):
+        """Record something a user of this robot's header should know (a kernel family that was not emitted, a predicted spill)."""
+        self.generation_notes.append(text)
+
+    def _report_generation_notes(self):
+        """The reference emits for any robot object and lets nvcc / the GPU find out (GRiDCodeGenerator.py:37-46: dynamic shared memory
+        forced above 12 joints; helpers/_topology_helpers.py:193-258: tables for any tree).  Here the straight-line design has limits
+        that are known at generation time -- 2m <= 64 lanes per wave group, an exchange region that must fit 160 KB of LDS, 512
+        registers per lane -- so the generator SAYS what it left out or expects to spill instead of leaving it to the build."""
+        import warnings
+        n = self.spec.n
+        if n > 32 and self.grad_schedule == "recompute":
+            from .emit import cores
+            tr = cores.core_gradient_recompute(self.spec, "fd")
+            mx, _ = tr.max_live()
+            self.predicted_live["forward_dynamics_gradient_kernel"] = mx
+            if mx > 480:
+                self.note("forward_dynamics_gradient_kernel keeps %d values alive per lane (the register file holds 512): expect it to spill "
+                          "to scratch; host.build_library refuses a kernel beyond GRID_MAX_SCRATCH = %s B per lane" % (mx, "8192"))
+        if self.generation_notes:
+            warnings.warn(GridGenerationWarning("%s (%d joints): %s" % (self.spec.name, n, "; ".join(self.generation_notes))), stacklevel=3)
+
     def output_file_name(self):
         return self.file_namespace + ".hip.h"
 
@@ -179,14 +233,16 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, SpatialAlgebraEmitMixin, Al
         if include_base_inertia:
             raise NotImplementedError("include_base_inertia adds data no reference emitter reads (helpers/_topology_helpers.py:5-12)")
         from .emit.trace import Tracer
-        saved = (Tracer.use_packed, Tracer.mixed, Tracer.dot_ways)
+        from .emit import algorithms as alg_mod
+        saved = (Tracer.use_packed, Tracer.mixed, Tracer.dot_ways, alg_mod.PRISMATIC_GRADIENT)
         Tracer.use_packed = self.packed
         Tracer.mixed = (self.precision == "mixed")
         Tracer.dot_ways = self.dot_ways
+        alg_mod.PRISMATIC_GRADIENT = self.prismatic_gradient
         try:
             self._gen_all_code_body(use_thread_group, include_base_inertia)
         finally:
-            Tracer.use_packed, Tracer.mixed, Tracer.dot_ways = saved
+            Tracer.use_packed, Tracer.mixed, Tracer.dot_ways, alg_mod.PRISMATIC_GRADIENT = saved
 
     def _gen_all_code_body(self, use_thread_group, include_base_inertia):
         self._chunks = []
@@ -195,6 +251,10 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, SpatialAlgebraEmitMixin, Al
         self.trace_stats = {}
         self.kernel_instances = []
         self.split_stats = {}
+        self.generation_notes = []
+        self.predicted_live = {}
+        if hasattr(self, "_lean_cache"):
+            del self._lean_cache
         n = self.spec.n
         file_notes = [
             "Interface is:",
@@ -267,12 +327,15 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, SpatialAlgebraEmitMixin, Al
         self.gen_inverse_dynamics_gradient(use_thread_group)
         self.gen_forward_dynamics_gradient(use_thread_group)
         self.gen_forward_dynamics_gradient_coop(use_thread_group)
-        self.gen_forward_dynamics_gradient_host()        # (after the cooperative kernel, which the wrappers dispatch for large robots)
+        self.gen_forward_dynamics_gradient_lean_decl()   # (its kernel is emitted last; the wrappers below dispatch it through this declaration)
+        self.gen_forward_dynamics_gradient_host()        # (after the cooperative kernels, which the wrappers dispatch for large robots)
         self.gen_forward_dynamics_gradient_rollout(use_thread_group)
         self.gen_forward_dynamics_gradient_wave(use_thread_group)       # (last: its kernel instance is appended, earlier kernels keep their object-cache keys)
         self.gen_wave_kernels_other(use_thread_group)
+        self.gen_forward_dynamics_gradient_lean(use_thread_group)       # (after everything else: no earlier kernel's object-cache key moves)
         self.gen_init_close_grid()
         self.gen_add_end_control_flow()
         self.gen_kernel_instance_list()
+        self._report_generation_notes()
         with open(self.output_file_name(), "w") as fh:
             fh.write(self.code_str)

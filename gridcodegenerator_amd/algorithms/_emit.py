@@ -71,7 +71,7 @@ class AlgorithmEmitMixin:
     # generic pieces
     # ------------------------------------------------------------------------------------------
     def _emit_traced_function(self, doc, notes, params, template, qualifiers, signature, tracer, store=None, order=None,
-                              fence_stmt="GRID_SCHED_FENCE();"):
+                              fence_stmt="GRID_SCHED_FENCE();", read_ahead=0):
         self.gen_add_func_doc(doc, notes, params, None)
         self.gen_add_code_line(template)
         self.gen_add_code_line(qualifiers)
@@ -79,12 +79,13 @@ class AlgorithmEmitMixin:
         self.gen_add_code_line("typedef C C2 __attribute__((ext_vector_type(2)));   // packed pair (d/dq, d/dqd): v_pk_* on gfx950")
         self.gen_add_code_line("typedef double D;   // high-precision type of the mixed-precision regions (Minv recursion, qdd = Minv (u - c))")
         ind = "    " * self.indent_level
-        lines = tracer.emit(indent=ind, order=order or self.emit_order, store=store, fence_every=self.fence_every, fence_stmt=fence_stmt)
+        lines = tracer.emit(indent=ind, order=order or self.emit_order, store=store, fence_every=self.fence_every, fence_stmt=fence_stmt,
+                            read_ahead=read_ahead)
         self.gen_add_raw("\n".join(lines))
         self.gen_add_end_function()
         self.trace_stats[signature.split("(")[0].split()[-1] + "/" + str(len(self.trace_stats))] = tracer.op_counts()
 
-    def _emit_core(self, name, doc, tracer, order=None, fence_stores=True, fence_stmt="GRID_SCHED_FENCE();"):
+    def _emit_core(self, name, doc, tracer, order=None, fence_stores=True, fence_stmt="GRID_SCHED_FENCE();", read_ahead=0):
         """template <T, C, In, Out> void name(const In &in, Out &out, const T gravity)."""
         self.core_stats[name] = dict(tracer.op_counts(), flops=tracer.flops())
         stride = max(1, int(getattr(self, "fence_stride", 1)))
@@ -101,7 +102,7 @@ class AlgorithmEmitMixin:
             "template <typename T, typename C, typename In, typename Out>",
             "__host__ __device__ __forceinline__",
             "void %s(const In &in, Out &out, const T gravity)" % name, tracer,
-            store=lambda dst, val: self._core_store(dst, val, fence_after_store), order=order, fence_stmt=fence_stmt)
+            store=lambda dst, val: self._core_store(dst, val, fence_after_store), order=order, fence_stmt=fence_stmt, read_ahead=read_ahead)
 
     @staticmethod
     def _core_store(dst, val, fence_after_store):
@@ -176,12 +177,17 @@ class AlgorithmEmitMixin:
         # (2nd argument = waves per SIMD).  Finer splits only run when there are fewer waves than SIMDs: no cap, no spills.
         # (the finer splits only in the fp32 arithmetic: the double regions of a mixed build would spill 60+ values under the cap)
         occ = 2 if (parts and len(parts) in getattr(self, "split_cap", (2,)) and n <= 12 and (len(parts) == 2 or self.precision == "fp32")) else self.waves_per_simd
-        self.gen_add_code_line("__global__ __launch_bounds__(GRID_MAX_THREADS%s)" % (", %d" % occ if occ > 1 else ""))
+        asym = bool(parts) and len(parts) == self.ASYM_SPLIT and all(isinstance(c, tuple) for (_, c) in parts) and n <= 8
+        if asym:            # one block of 8 waves per tile: two per SIMD, hence <= 256 registers; per-wave LDS = its largest output half
+            self.gen_add_code_line("__global__ __launch_bounds__(%d)" % (WAVE * len(parts)))
+        else:
+            self.gen_add_code_line("__global__ __launch_bounds__(GRID_MAX_THREADS%s)" % (", %d" % occ if occ > 1 else ""))
+        wave_lds = self.split_wave_lds(alg, parts) if asym else self.lds_per_wave(alg)
         self.gen_add_code_line(sig + " {", True)
         self.gen_add_code_lines([
             "extern __shared__ __align__(16) unsigned char s_grid_dyn[];",
             "const grid_tile_iter it(NUM_TIMESTEPS%s);" % (", %d" % len(parts) if parts else ""),
-            "T *s_wave = reinterpret_cast<T *>(s_grid_dyn) + it.wave_in_block*%d;" % self.lds_per_wave(alg),
+            "T *s_wave = reinterpret_cast<T *>(s_grid_dyn) + it.wave_in_block*%d;" % wave_lds,
             "for (int k0 = it.k0_first; k0 < NUM_TIMESTEPS; k0 += it.k0_step){",
         ])
         self.indent_level += 1
@@ -225,7 +231,7 @@ class AlgorithmEmitMixin:
             for pi, (pcore, cols) in enumerate(parts):
                 if isinstance(cols, tuple):         # ([d/dq columns], [d/dqd columns]): one flush per half
                     lo_cols, hi_cols = cols
-                    assert not direct and 64 * n * max(len(lo_cols), len(hi_cols)) <= self.lds_per_wave(alg)
+                    assert not direct and 64 * n * max(len(lo_cols), len(hi_cols)) <= wave_lds
                     self.gen_add_code_line("case %d: {" % pi, True)
                     self.gen_add_code_line("grid_out_colset2<T,%d,%d,%d,%s> out = {s_wave, d_%s, k0, it.lane, it.W, NUM_TIMESTEPS};   // d/dq columns %s, d/dqd columns %s"
                                            % (n_out, n, len(lo_cols), ",".join(str(c) for c in list(lo_cols) + list(hi_cols)), out_name, list(lo_cols), list(hi_cols)))
@@ -235,6 +241,8 @@ class AlgorithmEmitMixin:
                     continue
                 len0 = n * len(cols)
                 ch = chunk or self._chunk_for(len0)
+                if 64 * ch > self.lds_per_wave(alg):          # (a group of 5 columns of a 12-joint robot: 60 values per half, region sized for 48)
+                    ch = _largest_divisor_leq(len0, self.lds_per_wave(alg) // 64)
                 assert 64 * ch <= self.lds_per_wave(alg)
                 self.gen_add_code_line("case %d: {" % pi, True)
                 contiguous = list(cols) == list(range(cols[0], cols[-1] + 1))
@@ -263,6 +271,12 @@ class AlgorithmEmitMixin:
         self.gen_add_end_function()
         if not parts:
             self._emit_kernel_single_timing(alg, name, core, doc, out_name, primary, extras, has_gravity, accessor)
+
+    def split_wave_lds(self, alg, parts):
+        """LDS elements per wave of the asymmetric 8-way split kernel: inputs come by per-lane row loads (no staging), so a wave needs
+        only its largest output half (grid_out_colset2)."""
+        n = self.spec.n
+        return WAVE * n * max(max(len(c[0]), len(c[1])) for (_, c) in parts)
 
     def _emit_kernel_single_timing(self, alg, name, core, doc, out_name, primary, extras, has_gravity, accessor):
         """Latency twin of a kernel (reference: gen_*_kernel(..., single_call_timing=True), e.g.
@@ -476,8 +490,9 @@ class AlgorithmEmitMixin:
                 # sets of HALF columns (the d/dq and d/dqd halves of a column share only the prefix) where that lowers the maximum
                 parts, est = cores.optimal_column_sets(self.spec, S, full)
                 if self.split_half_columns:
-                    hparts, hest = cores.optimal_half_column_sets(self.spec, S, full)
-                    if hest < 0.98 * est and all(64 * n * max(len(lo), len(hi)) <= self.lds_per_wave("FD_DU") for (lo, hi) in hparts):
+                    hparts, hest = cores.optimal_half_column_sets(self.spec, S, full, per_value=self.split_flush_slots)
+                    est_cmp = est + self.split_flush_slots * n * max(2 * len(c_) for c_ in parts)       # (same measure for whole columns)
+                    if hest < 0.98 * est_cmp and all(64 * n * max(len(lo), len(hi)) <= self.lds_per_wave("FD_DU") for (lo, hi) in hparts):
                         parts, est = hparts, hest
             else:
                 parts, est = cores.balanced_column_split(self.spec, S, cost)
@@ -508,6 +523,16 @@ class AlgorithmEmitMixin:
         if self.grad_splits == "auto" and len(picked) > limit > 1:      # keep the coarsest, the finest and spread the rest
             idx = sorted(set(round(i * (len(picked) - 1) / (limit - 1)) for i in range(limit)))
             picked = [picked[i] for i in idx]
+        if use_sets and self.split_half_columns and self.split_asym and 2 * n >= self.ASYM_SPLIT and self.ASYM_SPLIT not in [S for (S, _, _) in picked]:
+            # ASYMMETRIC split over the two waves of every SIMD (blocks of 8 waves = one tile on one CU): four heavy groups for the waves
+            # dispatched first, which keep the lone-wave pace, four light ones -- d/dqd half-columns need neither the bias torques nor
+            # qdd nor the second RNEA pass -- for the waves behind them, whose cost counts split_asym-fold (they get the issue slots
+            # the older wave leaves: profiles/r03/two_waves_per_simd.md, 1.5-1.76x slower).  The symmetric 7-way split loses to the
+            # 4-way one at K = 16384 because every one of its waves repeats the whole prefix at the pair pace.
+            W8 = self.ASYM_SPLIT
+            hparts, hest = cores.optimal_half_column_sets(self.spec, W8, full, restarts=60, per_value=self.split_flush_slots,
+                                                          weights=[1.0] * (W8 // 2) + [float(self.split_asym)] * (W8 // 2))
+            picked.append((W8, hparts, hest))
         chosen = [(S, parts, max(cores._arith_ops(builder(c)) for c in parts)) for (S, parts, _) in picked]
         return base, chosen
 
@@ -545,18 +570,38 @@ class AlgorithmEmitMixin:
         self.gen_add_code_line("bool %s_split_launch(const int split, T *d_%s, const T *d_%s, const int %s, const robotModel<T> *d_robotModel, %sconst int num_timesteps,"
                                % (kernel_base.replace("_kernel", ""), out_name, pname, pstride, grav))
         self.gen_add_code_line("        int tiles_in_flight, const dim3 threads, hipStream_t stream) {", True)
-        self.gen_add_code_lines([
-            "int nthreads = threads.x*threads.y*threads.z;",
-            "if (nthreads <= 0){nthreads = GRID_WAVE_SIZE*split;}",
-            "nthreads = ((nthreads + GRID_WAVE_SIZE - 1)/GRID_WAVE_SIZE)*GRID_WAVE_SIZE; if (nthreads > GRID_MAX_THREADS){nthreads = GRID_MAX_THREADS;}",
-            "const int waves = nthreads/GRID_WAVE_SIZE;",
-            "const dim3 block(nthreads,1,1);",
-            "const size_t lds_bytes = grid_lds_bytes<T>(block, %d);" % self.lds_per_wave(alg),
-            "if (tiles_in_flight < 1){tiles_in_flight = 1;}",
-            "const dim3 grid((tiles_in_flight*split + waves - 1)/waves,1,1);     // (surplus waves of the last block idle)",
-        ])
+        asym_S = [S for (S, parts, _) in chosen if S == self.ASYM_SPLIT and all(isinstance(c, tuple) for c in parts) and self.spec.n <= 8]
+        asym_lds = {S: self.split_wave_lds(alg, [(None, c) for c in parts]) for (S, parts, _) in chosen if S in asym_S}
+        if asym_S:
+            self.gen_add_code_lines([
+                "int nthreads = threads.x*threads.y*threads.z;",
+                "const bool asym = %s;      // the asymmetric split: ALWAYS one block of `split` waves per tile (heavy groups = the waves dispatched first)" % " || ".join("split == %d" % S for S in asym_S),
+                "if (nthreads <= 0 || asym){nthreads = GRID_WAVE_SIZE*split;}",
+                "nthreads = ((nthreads + GRID_WAVE_SIZE - 1)/GRID_WAVE_SIZE)*GRID_WAVE_SIZE; if (nthreads > GRID_MAX_THREADS && !asym){nthreads = GRID_MAX_THREADS;}",
+                "const int waves = nthreads/GRID_WAVE_SIZE;",
+                "const dim3 block(nthreads,1,1);",
+                "size_t lds_bytes = grid_lds_bytes<T>(block, %d);" % self.lds_per_wave(alg),
+                "if (tiles_in_flight < 1){tiles_in_flight = 1;}",
+                "const dim3 grid((tiles_in_flight*split + waves - 1)/waves,1,1);     // (surplus waves of the last block idle)",
+            ])
+        else:       # (the text every library without such a kernel has had since round 3: this block is part of every kernel's cache key)
+            self.gen_add_code_lines([
+                "int nthreads = threads.x*threads.y*threads.z;",
+                "if (nthreads <= 0){nthreads = GRID_WAVE_SIZE*split;}",
+                "nthreads = ((nthreads + GRID_WAVE_SIZE - 1)/GRID_WAVE_SIZE)*GRID_WAVE_SIZE; if (nthreads > GRID_MAX_THREADS){nthreads = GRID_MAX_THREADS;}",
+                "const int waves = nthreads/GRID_WAVE_SIZE;",
+                "const dim3 block(nthreads,1,1);",
+                "const size_t lds_bytes = grid_lds_bytes<T>(block, %d);" % self.lds_per_wave(alg),
+                "if (tiles_in_flight < 1){tiles_in_flight = 1;}",
+                "const dim3 grid((tiles_in_flight*split + waves - 1)/waves,1,1);     // (surplus waves of the last block idle)",
+            ])
         self.gen_add_code_line("switch (split){", True)
         for (S, parts, worst) in chosen:
+            if S in asym_S:
+                assert 4 * S * asym_lds[S] <= 65536
+                self.gen_add_code_line("case %d: lds_bytes = grid_lds_bytes<T>(block, %d); %s_split%d<T><<<grid,block,lds_bytes,stream>>>(d_%s,d_%s,%s,d_robotModel,%snum_timesteps); return true;"
+                                       % (S, asym_lds[S], kernel_base, S, out_name, pname, pstride, "gravity," if has_gravity else ""))
+                continue
             self.gen_add_code_line("case %d: %s_split%d<T><<<grid,block,lds_bytes,stream>>>(d_%s,d_%s,%s,d_robotModel,%snum_timesteps); return true;"
                                    % (S, kernel_base, S, out_name, pname, pstride, "gravity," if has_gravity else ""))
         self.gen_add_code_line("default: return false;")
@@ -1012,6 +1057,8 @@ class AlgorithmEmitMixin:
             "if (USE_QDD_MINV_FLAG) {forward_dynamics_gradient_kernel<T>@L(hd_data->d_df_du,hd_data->d_q_qd_u,stride_q_qd,hd_data->d_qdd,hd_data->d_Minv,d_robotModel,gravity,num_timesteps);}",
             # the reference-named wrappers serve the reference's callers: where the tile-cooperative kernel is the faster one
             # (FD_DU_COOP_AUTO_MIN_TILES: large robots) they launch it -- same outputs to round-off, blocks/threads then unused
+            "else if (FD_DU_LEAN_AUTO_MIN_TILES > 0 && (num_timesteps + GRID_WAVE_SIZE - 1)/GRID_WAVE_SIZE >= FD_DU_LEAN_AUTO_MIN_TILES && "
+            "forward_dynamics_gradient_lean_launch<T>(hd_data->d_df_du,hd_data->d_q_qd_u,stride_q_qd,d_robotModel,gravity,num_timesteps,0,@S)) {}",
             "else if (FD_DU_COOP_AUTO_MIN_TILES > 0 && (num_timesteps + GRID_WAVE_SIZE - 1)/GRID_WAVE_SIZE >= FD_DU_COOP_AUTO_MIN_TILES && "
             "forward_dynamics_gradient_coop_launch<T>(hd_data->d_df_du,hd_data->d_q_qd_u,stride_q_qd,d_robotModel,gravity,num_timesteps,0,@S)) {}",
             "else                   {forward_dynamics_gradient_kernel<T>@L(hd_data->d_df_du,hd_data->d_q_qd_u,stride_q_qd,d_robotModel,gravity,num_timesteps);}"]
@@ -1131,6 +1178,7 @@ class AlgorithmEmitMixin:
     # ------------------------------------------------------------------------------------------
     # tile-cooperative forward-dynamics gradient: the waves of a block share one tile of 64 configurations
     # ------------------------------------------------------------------------------------------
+    ASYM_SPLIT = 8          # the asymmetric split's factor: 8 waves per tile, launched as ONE block of 512 threads (two waves per SIMD of a CU)
     COOP_WAVES = 4
     FLUSH_SLOTS_PER_COLUMN = 400      # instruction-issue slots one gradient column (two flushes of n values) costs a lone wavefront
 
@@ -1325,6 +1373,9 @@ class AlgorithmEmitMixin:
         lds_elems = xch_off + WAVE * slots.count
         if 4 * lds_elems > 160 * 1024:
             self.gen_add_code_line("const int FD_DU_COOP_WAVES = 0; // the exchange region of this robot does not fit the 160 KB of LDS")
+            self.note("no tile-cooperative kernel (FD_DU_COOP_WAVES = 0): its exchange region -- the non-zero upper triangle of Minv, %d slots of "
+                      "256 B, plus staging -- needs %d KB of the CU's 160 KB of LDS; the forward-dynamics gradient falls back to the column-split / "
+                      "unsplit recomputing kernels, which keep Minv in registers" % (slots.count, 4 * lds_elems // 1024))
             self._emit_no_coop()
             return
         self.coop_stats = dict(groups=[(r, list(c)) for (r, c) in groups], slots=slots.count, lds_bytes=4 * lds_elems)
@@ -1435,6 +1486,13 @@ class AlgorithmEmitMixin:
     # ------------------------------------------------------------------------------------------
     # wave-per-configuration forward-dynamics gradient: the lanes of ONE wavefront share a configuration
     # ------------------------------------------------------------------------------------------
+    def _wave_occupancy_arg(self):
+        """Second __launch_bounds__ argument of the wave-per-configuration kernels (waves per SIMD the compiler must leave room for).
+        Large robots: 2 -- a block is one configuration, at 295 registers 512 blocks were resident and the time per launch doubled
+        from K = 1024 on; at <= 256 registers 1024 are (experimental wave_occupancy; measured in profiles/r04)."""
+        occ = int(self.wave_occupancy)
+        return ", %d" % occ if occ > 1 else ""
+
     def _emit_no_wave(self):
         self.gen_add_code_line("const int FD_DU_WAVE_WAVES = 0; // no wave-per-configuration kernel for this robot")
         self.gen_add_code_line("const int FD_DU_WAVE_AUTO_MAX_K = 0;")
@@ -1452,6 +1510,10 @@ class AlgorithmEmitMixin:
         n = self.spec.n
         groups = wave.wave_groups(self.spec) if self.precision != "fp64" else None
         if not groups:
+            if self.precision != "fp64":
+                self.note("no wave-per-configuration kernels (FD_DU_WAVE_WAVES = 0): a wave holds the 2m gradient columns of its group of "
+                          "base-rooted trees on its 64 lanes, and a group of this robot has more than 32 joints; small batches run the "
+                          "lane-per-configuration kernels")
             self._emit_no_wave()
             return
         W = len(groups)
@@ -1511,7 +1573,7 @@ class AlgorithmEmitMixin:
                                "d_robotModel is the pointer to the initialized model specific helpers on the GPU (unused: constants are baked in)",
                                "gravity is the gravity constant", "NUM_TIMESTEPS is the number of configurations"], None)
         self.gen_add_code_line("template <typename T, typename C = typename grid_compute<T>::type>")
-        self.gen_add_code_line("__global__ __launch_bounds__(%d)" % (W * WAVE))
+        self.gen_add_code_line("__global__ __launch_bounds__(%d%s)" % (W * WAVE, self._wave_occupancy_arg()))
         self.gen_add_code_line("void forward_dynamics_gradient_kernel_wave(T *d_df_du, const T *d_q_qd_u, const int stride_q_qd_u, "
                                "const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS) {", True)
         self.gen_add_code_lines([
@@ -1643,7 +1705,7 @@ class AlgorithmEmitMixin:
                                   ["d_%s is the output buffer, %d values per configuration" % (out_name, n_out),
                                    "d_%s is the input buffer; stride_%s is the stride between configurations in it" % (in_name, in_name)], None)
             self.gen_add_code_line("template <typename T, typename C = typename grid_compute<T>::type>")
-            self.gen_add_code_line("__global__ __launch_bounds__(%d)" % (W * WAVE))
+            self.gen_add_code_line("__global__ __launch_bounds__(%d%s)" % (W * WAVE, self._wave_occupancy_arg()))
             self.gen_add_code_line(sig + " {", True)
             self.gen_add_code_lines([
                 "extern __shared__ __align__(16) unsigned char s_grid_dyn[];",
@@ -1723,6 +1785,166 @@ class AlgorithmEmitMixin:
                 self.gen_add_code_line("if (alg == %d){f = reinterpret_cast<const void *>(&%s_kernel_wave<T>);}" % (a, base))
             self.gen_add_code_line("if (f == nullptr){return false;}")
             self.gen_add_code_line("gpuErrchk(hipFuncGetAttributes(attr, f)); return true;")
+        self.gen_add_end_function()
+
+    # ------------------------------------------------------------------------------------------
+    # register-lean tile-cooperative forward-dynamics gradient: EIGHT wavefronts share one tile, two per SIMD
+    # ------------------------------------------------------------------------------------------
+    def _lean_prepare(self):
+        """(slots, plan, stage, lds_elems) of the register-lean kernel, or None when this robot / arithmetic has none (cached: the
+        declarations are emitted ahead of the host wrappers, the kernel itself last)."""
+        if hasattr(self, "_lean_cache"):
+            return self._lean_cache
+        n = self.spec.n
+        W = cores.LEAN_WAVES
+        self._lean_cache = None
+        if n <= 12 or self.precision != "fp32" or self.grad_schedule != "recompute":
+            return None
+        slots, plan = cores.lean_plan(self.spec, W, **self.lean_plan_options)
+        if self.lean_probe == "prefix":             # (experiment: phases 0-3 only -- what a tile costs before its first gradient column)
+            for (role, items) in plan:
+                role.hoist = []
+            plan = [(role, []) for (role, items) in plan]
+        elif self.lean_probe == "older":            # (experiment: only the waves dispatched first keep their columns)
+            plan = [(role, items if w < W // 2 else []) for w, (role, items) in enumerate(plan)]
+        elif self.lean_probe == "younger":
+            plan = [(role, items if w >= W // 2 else []) for w, (role, items) in enumerate(plan)]
+        stage = WAVE * n                             # per wave: one input piece / one gradient half-column per flush
+        lds_elems = W * stage + WAVE * slots.count
+        if 4 * lds_elems > 160 * 1024 or 7 * n > W * (stage // WAVE):
+            self.note("no register-lean 8-wave tile-cooperative kernel (FD_DU_LEAN_WAVES = 0): exchange region + input table + 8 staging "
+                      "regions need %d KB of the CU's 160 KB of LDS" % (4 * lds_elems // 1024))
+            return None
+        self._lean_cache = (slots, plan, stage, lds_elems)
+        return self._lean_cache
+
+    def gen_forward_dynamics_gradient_lean_decl(self):
+        """Constants and forward declarations of the register-lean kernel's launcher, ahead of the reference-named host wrappers (which
+        dispatch it where it is the fastest kernel); the kernel itself is emitted last (gen_forward_dynamics_gradient_lean)."""
+        prep = self._lean_prepare()
+        W = cores.LEAN_WAVES
+        if prep is None:
+            self.gen_add_code_line("const int FD_DU_LEAN_WAVES = 0; // no register-lean tile-cooperative kernel for this robot / arithmetic")
+            self.gen_add_code_line("const int FD_DU_LEAN_AUTO_MIN_TILES = 0;")
+        else:
+            slots, plan, stage, lds_elems = prep
+            self.gen_add_code_line("const int FD_DU_LEAN_WAVES = %d; // wavefronts per block of the register-lean tile-cooperative kernel (block = %d threads, one tile)" % (W, W * WAVE))
+            # measured against the 4-wave kernel (profiles/r04/lean_sweep.txt, Atlas-30, us per launch, 4 waves -> 8 waves): K = 64 54.3 -> 40.0,
+            # 4096 60.8 -> 47.9, 16384 67.0 -> 52.8, 32768 130.6 -> 106.7, 65536 306.9 -> 290.8, 131072 624 -> 568: every batch size
+            self.gen_add_code_line("const int FD_DU_LEAN_AUTO_MIN_TILES = %d; // automatic choice of the register-lean kernel from this many tiles on (0: only on request)" % self.lean_auto_min_tiles)
+            self.gen_add_code_line("const int FD_DU_LEAN_SHARED_MEM_COUNT = %d; // dynamic LDS in T elements: %d staging regions of %d + %d exchange slots x 64 lanes"
+                                   % (lds_elems, W, stage, slots.count))
+        self.gen_add_code_lines(["template <typename T>", "__host__ inline",
+                                 "bool forward_dynamics_gradient_lean_launch(T *d_df_du, const T *d_q_qd_u, const int stride_q_qd_u, const robotModel<T> *d_robotModel, "
+                                 "const T gravity, const int num_timesteps, int tile_blocks, hipStream_t stream);", ""])
+
+    def _emit_no_lean(self):
+        self.gen_add_code_lines(["template <typename T>", "__host__ inline",
+                                 "bool forward_dynamics_gradient_lean_launch(T *, const T *, const int, const robotModel<T> *, const T, const int, int, hipStream_t) {return false;}",
+                                 "template <typename T>", "__host__ inline",
+                                 "bool forward_dynamics_gradient_lean_attributes(hipFuncAttributes *) {return false;}", ""])
+
+    def gen_forward_dynamics_gradient_lean(self, use_thread_group=False):
+        """`forward_dynamics_gradient_kernel_coop8`: one block of EIGHT wavefronts per tile of 64 configurations -- two per SIMD, at most
+        256 registers each -- for large robots in the fp32 arithmetic.  The 4-wave kernel (`..._kernel_coop`) gives every wave a
+        SIMD of its own and 464 registers; a lone wave issues one vector instruction per 4 cycles on a SIMD that could take two, and
+        39 % of its cycles are waits nobody fills.  Here the cores are built to need HALF a SIMD's registers (cores.CoopSlots.enable_lean,
+        cores.lean_plan, alg.minv_backward_lean / minv_forward_lean) so that a second wave fills those slots.  The reference spreads a
+        configuration over a 512-thread block (GRiDCodeGenerator.py:72-83; algorithms/_inverse_dynamics_gradient.py:199-246,501-540:
+        threads = gradient columns); this is the wave64 counterpart with lanes = configurations and waves = (column half) work items."""
+        n = self.spec.n
+        W = cores.LEAN_WAVES
+        prep = self._lean_prepare()
+        if prep is None:
+            self._emit_no_lean()
+            return
+        slots, plan, stage, lds_elems = prep
+        piece = n
+        xch_off = W * stage
+        self.lean_stats = dict(plan=[(repr(r), list(items)) for (r, items) in plan], slots=slots.count, lds_bytes=4 * lds_elems, model=dict(slots.lean_model))
+        names = []
+        for w, (role, items) in enumerate(plan):
+            cname = "forward_dynamics_gradient_lean_core_w%d" % w
+            tr = cores.core_gradient_recompute(self.spec, "fd", cols=items, coop=(role, slots))
+            self._emit_core(cname, "Register-lean tile-cooperative forward-dynamics gradient, wave %d of %d: %r; gradient half-columns (column, 0 = d/dq | 1 = d/dqd) %s"
+                            % (w, W, role, list(items)), tr, order="creation", read_ahead=self.lean_read_ahead)
+            names.append((cname, list(tr.run_bases)))
+        n_out = self.io_layout["FD_DU"]["n_out"]
+        self.kernel_instances.append("__global__ void @NS::forward_dynamics_gradient_kernel_coop8<T>(T *, const T *, const int, "
+                                     "const @NS::robotModel<T> *, const T, const int);")
+        self.gen_add_func_doc("Computes the gradient of forward dynamics (register-lean tile-cooperative: %d wavefronts, two per SIMD, share each tile of 64 configurations)" % W,
+                              ["launch with EXACTLY %d threads per block and FD_DU_LEAN_SHARED_MEM_COUNT*sizeof(T) of dynamic LDS" % (W * WAVE),
+                               "(use forward_dynamics_gradient_lean_launch); blocks grid-stride over the tiles",
+                               "LDS: [%d staging regions | exchange region]; before the second barrier the staging regions park U and 1/D of the Minv recursion" % W],
+                              ["d_df_du is the output buffer, %d values per configuration" % n_out,
+                               "d_q_qd_u is the input buffer, %d values read per configuration" % (3 * n),
+                               "stride_q_qd_u is the stride between configurations in d_q_qd_u",
+                               "d_robotModel is the pointer to the initialized model specific helpers on the GPU (unused: constants are baked in)",
+                               "gravity is the gravity constant", "NUM_TIMESTEPS is the number of configurations"], None)
+        self.gen_add_code_line("template <typename T, typename C = typename grid_compute<T>::type>")
+        self.gen_add_code_line("__global__ __launch_bounds__(%d)" % (W * WAVE))
+        self.gen_add_code_line("void forward_dynamics_gradient_kernel_coop8(T *d_df_du, const T *d_q_qd_u, const int stride_q_qd_u, "
+                               "const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS) {", True)
+        self.gen_add_code_lines([
+            "extern __shared__ __align__(16) unsigned char s_grid_dyn[];",
+            "grid_tile_iter it(NUM_TIMESTEPS);              // lane / wave bookkeeping only: the tile loop below is per BLOCK",
+            "T *s_wave = reinterpret_cast<T *>(s_grid_dyn) + it.wave_in_block*%d;" % stage,
+            "T *s_xch = reinterpret_cast<T *>(s_grid_dyn) + %d;" % xch_off,
+            "const int nblocks = grid_num_blocks();",
+            "const int bid = grid_block_id();",
+            "if (grid_block_threads() != %d){return;}    // (the launcher guarantees it; a wrong shape must not deadlock the barriers)" % (W * WAVE),
+            "for (int k0 = bid*GRID_WAVE_SIZE; k0 < NUM_TIMESTEPS; k0 += nblocks*GRID_WAVE_SIZE){",
+        ])
+        self.indent_level += 1
+        self.gen_add_code_line("T s_q_qd_u[%d];" % (3 * n))
+        self._emit_load("s_q_qd_u", "d_q_qd_u", 3 * n, "stride_q_qd_u", piece)
+        self.gen_add_code_line("const unsigned xb = (unsigned)reinterpret_cast<unsigned long long>(s_xch) + (unsigned)sizeof(T)*it.lane;")
+        self.gen_add_code_line("const grid_in_lean<T> in = {s_q_qd_u, s_q_qd_u + %d, s_q_qd_u + %d, s_xch, it.lane, xb, xb + 256u*GRID_WAVE_SIZE*(unsigned)sizeof(T), "
+                               "xb - 256u*GRID_WAVE_SIZE*(unsigned)sizeof(T)};" % (n, 2 * n))
+        self.gen_add_code_line("switch (it.wave_in_block){", True)
+        for w, (cname, bases) in enumerate(names):
+            self.gen_add_code_line("case %d: {" % w, True)
+            if bases:
+                self.gen_add_code_line("grid_out_runs<T,%d,%d,%s> out = {s_wave, d_df_du, k0, it.lane, it.W, NUM_TIMESTEPS};"
+                                       % (n_out, n, ",".join(str(b) for b in bases)))
+            else:
+                self.gen_add_code_line("grid_out_ptr<T> out = {nullptr};     // (this core stores nothing)")
+            self.gen_add_code_line("%s<T,C>(in, out, gravity);" % cname)
+            self.gen_add_code_line("break;")
+            self.gen_add_end_control_flow()
+        self.gen_add_code_line("default: break;")
+        self.gen_add_end_control_flow()
+        self.gen_add_code_line("grid_block_sync();     // the exchange region and the staging regions are rewritten by the next tile")
+        self.gen_add_end_control_flow()
+        self.gen_add_end_function()
+        self.gen_add_func_doc("Launch the register-lean tile-cooperative forward-dynamics-gradient kernel (asynchronous, on `stream`)",
+                              ["tile_blocks <= 0: one block per tile of 64 configurations (capped at 4*SUGGESTED_MAX_BLOCKS)",
+                               "returns false when this robot has no such kernel"], [], None)
+        self.gen_add_code_line("template <typename T>")
+        self.gen_add_code_line("__host__ inline")
+        self.gen_add_code_line("bool forward_dynamics_gradient_lean_launch(T *d_df_du, const T *d_q_qd_u, const int stride_q_qd_u, const robotModel<T> *d_robotModel, "
+                               "const T gravity, const int num_timesteps, int tile_blocks, hipStream_t stream) {", True)
+        self.gen_add_code_lines([
+            "const size_t lds_bytes = (size_t)FD_DU_LEAN_SHARED_MEM_COUNT*sizeof(T);",
+            "static thread_local int configured_device = -1;        // > 64 KiB of dynamic LDS must be enabled once per device",
+            "int dev = 0; gpuErrchk(hipGetDevice(&dev));",
+            "if (lds_bytes > 65536 && configured_device != dev){",
+            "    gpuErrchk(hipFuncSetAttribute(reinterpret_cast<const void *>(&forward_dynamics_gradient_kernel_coop8<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));",
+            "    configured_device = dev;",
+            "}",
+            "const int tiles = (num_timesteps + GRID_WAVE_SIZE - 1)/GRID_WAVE_SIZE;",
+            "if (tile_blocks <= 0 || tile_blocks > tiles){tile_blocks = tiles;}",
+            "if (tile_blocks > 4*SUGGESTED_MAX_BLOCKS){tile_blocks = 4*SUGGESTED_MAX_BLOCKS;}",
+            "forward_dynamics_gradient_kernel_coop8<T><<<dim3(tile_blocks,1,1),dim3(%d,1,1),lds_bytes,stream>>>(d_df_du,d_q_qd_u,stride_q_qd_u,d_robotModel,gravity,num_timesteps);" % (W * WAVE),
+            "gpuErrchk(hipGetLastError());",
+            "return true;",
+        ])
+        self.gen_add_end_function()
+        self.gen_add_func_doc("hipFuncGetAttributes of the register-lean tile-cooperative kernel", ["returns false when this robot has none"], [], None)
+        self.gen_add_code_line("template <typename T>")
+        self.gen_add_code_line("__host__ inline")
+        self.gen_add_code_line("bool forward_dynamics_gradient_lean_attributes(hipFuncAttributes *attr) {", True)
+        self.gen_add_code_line("gpuErrchk(hipFuncGetAttributes(attr, reinterpret_cast<const void *>(&forward_dynamics_gradient_kernel_coop8<T>))); return true;")
         self.gen_add_end_function()
 
     def _emit_no_coop(self):

@@ -29,7 +29,8 @@ struct grid_handle {
     int max_timesteps;
     int split[5];   // per algorithm: 0 = auto, 1 = never split, S = force the S-way column-split kernel
     int pipeline[5];   // per algorithm: 0 = auto (single kernel), 1 = single kernel, 2 = two-pass (workspace) variant
-    int coop[5];       // per algorithm: 0 = auto, 1 = never, 2 = always the tile-cooperative kernel (where generated)
+    int coop[5];       // per algorithm: 0 = auto, 1 = never, 2 = always the tile-cooperative kernel (where generated), 3 = always its
+                       // register-lean 8-wave variant (where generated)
     int wave[5];       // per algorithm: 0 = auto, 1 = never, 2 = always the wave-per-configuration kernel (where generated)
     int unsplit_regs[5];   // registers of the unsplit kernel (hipFuncGetAttributes at init): <= 256 means two waves share a SIMD
     T *d_workspace; size_t workspace_bytes; hipStream_t workspace_stream; bool workspace_busy;
@@ -244,13 +245,19 @@ static int effective_split(const grid_handle *h, int alg, int K) {
 // from the header (FD_DU_COOP_AUTO_MIN_TILES, with the measurements behind it): every batch size for large robots in fp32, full
 // chips only in the mixed arithmetic, small robots only on request.
 static bool coop_available(int alg) { return alg == GRID_ALG_FD_DU && G::FD_DU_COOP_WAVES > 0; }
-static bool use_coop(const grid_handle *h, int alg, int K, const float *d_qdd, const float *d_Minv) {
-    if (!coop_available(alg) || d_qdd != nullptr || d_Minv != nullptr || h->coop[alg] == 1) return false;
-    if (h->coop[alg] == 2) return true;
-    if (h->split[alg] != 0 || h->pipeline[alg] == 2 || h->wave[alg] == 2) return false;          // an explicit choice of another variant wins
+static bool lean_available(int alg) { return alg == GRID_ALG_FD_DU && G::FD_DU_LEAN_WAVES > 0; }
+// 0: neither, 1: the 4-wave tile-cooperative kernel, 2: its register-lean 8-wave variant (two waves per SIMD, <= 256 registers each)
+static int coop_variant(const grid_handle *h, int alg, int K, const float *d_qdd, const float *d_Minv) {
+    if (alg < 0 || alg > 4 || d_qdd != nullptr || d_Minv != nullptr || h->coop[alg] == 1) return 0;
+    if (h->coop[alg] == 3) return lean_available(alg) ? 2 : 0;
+    if (h->coop[alg] == 2) return coop_available(alg) ? 1 : 0;
+    if (h->split[alg] != 0 || h->pipeline[alg] == 2 || h->wave[alg] == 2) return 0;              // an explicit choice of another variant wins
     const int tiles = (K + G::GRID_WAVE_SIZE - 1) / G::GRID_WAVE_SIZE;
-    return G::FD_DU_COOP_AUTO_MIN_TILES > 0 && tiles >= G::FD_DU_COOP_AUTO_MIN_TILES;     // (the generated header knows: see its comment)
+    if (lean_available(alg) && G::FD_DU_LEAN_AUTO_MIN_TILES > 0 && tiles >= G::FD_DU_LEAN_AUTO_MIN_TILES) return 2;
+    if (coop_available(alg) && G::FD_DU_COOP_AUTO_MIN_TILES > 0 && tiles >= G::FD_DU_COOP_AUTO_MIN_TILES) return 1;      // (the generated header knows: see its comment)
+    return 0;
 }
+static bool use_coop(const grid_handle *h, int alg, int K, const float *d_qdd, const float *d_Minv) { return coop_variant(h, alg, K, d_qdd, d_Minv) != 0; }
 
 // Wave-per-configuration kernels (all five algorithms): one block per configuration, the lanes of a wavefront are the gradient
 // columns / Minv columns / joints of a group of base-rooted trees.  A configuration then takes as long as its longest group's chain
@@ -271,7 +278,7 @@ static bool use_wave(const grid_handle *h, int alg, int K, const float *d_qdd, c
     if (!wave_available(alg) || d_Minv != nullptr || h->wave[alg] == 1) return false;
     if (alg == GRID_ALG_FD_DU && d_qdd != nullptr) return false;       // (precomputed qdd/Minv: the lane-per-configuration kernel)
     if (h->wave[alg] == 2) return true;
-    if (h->split[alg] != 0 || h->pipeline[alg] == 2 || h->coop[alg] == 2) return false;
+    if (h->split[alg] != 0 || h->pipeline[alg] == 2 || h->coop[alg] >= 2) return false;
     // A caller that passes a launch shape means blocks of `threads` CONFIGURATIONS (the reference's <<<block_dimms, thread_dimms>>>,
     // lane-per-configuration here); in the wave-per-configuration kernels a block IS one configuration, so the same numbers would mean
     // blocks*1 configurations in flight, each block walking K/blocks of them serially.  The automatic choice therefore keeps to the
@@ -323,7 +330,8 @@ static int launch_alg(grid_handle *h, int alg, float *d_out, const float *d_in, 
         int tile_blocks = 0;
         if (blocks > 0) { const long long cfgs = (long long)blocks * (threads > 0 ? threads : G::GRID_WAVE_SIZE);
                           tile_blocks = (int)((cfgs + G::GRID_WAVE_SIZE - 1) / G::GRID_WAVE_SIZE); }
-        G::forward_dynamics_gradient_coop_launch<T>(d_out, d_in, stride, h->d_robotModel, gravity, K, tile_blocks, s);
+        if (coop_variant(h, alg, K, d_qdd, d_Minv) == 2) G::forward_dynamics_gradient_lean_launch<T>(d_out, d_in, stride, h->d_robotModel, gravity, K, tile_blocks, s);
+        else G::forward_dynamics_gradient_coop_launch<T>(d_out, d_in, stride, h->d_robotModel, gravity, K, tile_blocks, s);
         return grid_check("kernel launch (tile-cooperative)");
     }
     if (use_pipeline(h, alg, d_qdd, d_Minv)) {
@@ -463,15 +471,25 @@ int grid_get_split(grid_handle *h, int alg, int num_timesteps) {
 }
 
 int grid_coop_available(int alg) { return coop_available(alg) ? 1 : 0; }
+int grid_lean_available(int alg) { return lean_available(alg) ? 1 : 0; }
 int grid_set_coop(grid_handle *h, int alg, int mode) {
-    if (h == nullptr || alg < 0 || alg > 4 || mode < 0 || mode > 2) { g_last_error = "grid_set_coop: bad arguments"; return -1; }
+    if (h == nullptr || alg < 0 || alg > 4 || mode < 0 || mode > 3) { g_last_error = "grid_set_coop: bad arguments"; return -1; }
     if (mode == 2 && !coop_available(alg)) { g_last_error = "grid_set_coop: no tile-cooperative kernel was generated for this robot/algorithm"; return -1; }
+    if (mode == 3 && !lean_available(alg)) { g_last_error = "grid_set_coop: no register-lean tile-cooperative kernel was generated for this robot/algorithm"; return -1; }
     h->coop[alg] = mode;
     return 0;
 }
 int grid_get_coop(grid_handle *h, int alg, int num_timesteps) {
     if (h == nullptr || alg < 0 || alg > 4) return -1;
-    return use_coop(h, alg, num_timesteps, nullptr, nullptr) ? 1 : 0;
+    return coop_variant(h, alg, num_timesteps, nullptr, nullptr);
+}
+int grid_kernel_attributes_lean(int alg, int *out) {
+    if (out == nullptr || !lean_available(alg)) { g_last_error = "grid_kernel_attributes_lean: not available"; return -1; }
+    hipFuncAttributes a;
+    G::forward_dynamics_gradient_lean_attributes<T>(&a);
+    if (int rc = grid_check("grid_kernel_attributes_lean")) return rc;
+    out[0] = a.numRegs; out[1] = (int)a.sharedSizeBytes; out[2] = (int)a.localSizeBytes; out[3] = a.maxThreadsPerBlock;
+    return 0;
 }
 int grid_kernel_attributes_coop(int alg, int *out) {
     if (out == nullptr || !coop_available(alg)) { g_last_error = "grid_kernel_attributes_coop: not available"; return -1; }

@@ -81,8 +81,17 @@ def fxv(tr, a, b):
     ]
 
 
+PRISMATIC_GRADIENT = "corrected"        # module-wide switch, set per build by GRiDCodeGenerator(prismatic_gradient=...)
+
+
 def fxS(tr, s, f):
-    """crf(e_s) f -- force cross product with the joint axis (see oracle docstring: prismatic fix)."""
+    """crf(e_s) f -- force cross product with the joint axis: the seed of the d/dq column of joint s's own joint in the backward pass
+    of the RNEA gradient.  The reference uses -mxS(S, f) there, the MOTION cross product applied to a force (_test.py:311,437, emitted
+    identically): the same thing for revolute joints (crm(S) is block-diagonal and antisymmetric), different -- and at odds with finite
+    differences -- for prismatic ones (tests/test_oracle.py).  PRISMATIC_GRADIENT = "reference" reproduces the reference's choice so
+    that a prismatic robot's gradients can be held to the reference's own numbers; "corrected" (default) is the force cross product."""
+    if PRISMATIC_GRADIENT == "reference":
+        return [-x for x in mxS(tr, s, f)]
     S = [tr.const(1.0 if i == s else 0.0) for i in range(6)]
     return fxv(tr, S, f)
 
@@ -242,6 +251,115 @@ def _direct_minv(tr, spec, X, I, between=None, on_final=None):
                 continue
             Fn[(j, k)] = Fjk
     return Minv
+
+
+def minv_backward_lean(tr, spec, I, X_back, publish, joints, cols=None):
+    """Backward pass of the Minv recursion (_direct_minv, first loop) over whole base-rooted trees (`joints`), for blocks whose waves
+    share the recursion through LDS: every value the forward pass needs is PUBLISHED where it is produced -- publish("U", j, r, v)
+    r = 0..5, publish("D", j, 0, 1/D_j), publish("M", j, k, backward-pass value of Minv[j][k]) for k in subtree(j) -- and nothing is
+    carried in registers.  X_back(j): X_j(q_j) built from re-read sin / cos.  cols: only these columns' entries and F recursions (two
+    waves may divide a large tree's columns; each then repeats the articulated-inertia chain, whose U and 1/D both publish -- the
+    same values to the same words)."""
+    n = spec.n
+    inside = set(joints)
+    wanted = (lambda k: True) if cols is None else (lambda k, cs=set(cols): k in cs)
+    IA = {}
+
+    def IA_of(j):
+        if j not in IA:
+            IA[j] = [[I[j][min(r, c)][max(r, c)] for c in range(6)] for r in range(6)]
+        return IA[j]
+    F = {}
+    with tr.mixed_region():
+        for j in range(n - 1, -1, -1):
+            if j not in inside:
+                continue
+            p, s = spec.parent[j], spec.S_ind[j]
+            IAj = IA_of(j)
+            Uj = [IAj[r][s] for r in range(6)]
+            Dj = tr.rcp(Uj[s])
+            if p != -1:                      # (the forward pass of a base joint needs neither)
+                for r in range(6):
+                    publish("U", j, r, Uj[r])
+                publish("D", j, 0, Dj)
+            Mj = {j: Dj}
+            mine = [k for k in spec.subtree[j] if wanted(k)]
+            for k in mine:
+                if k != j:
+                    Fjk = F.get((j, k))
+                    Mj[k] = -(Dj * Fjk[s]) if Fjk is not None else tr.zero()
+            for k in mine:
+                publish("M", j, k, Mj[k])
+            if p == -1:
+                continue
+            Xj = X_back(j)
+            for k in mine:
+                Fjk = F.pop((j, k), None)
+                upd = [Uj[r] * Mj[k] for r in range(6)]
+                Fjk = upd if Fjk is None else vadd(Fjk, upd)
+                F[(p, k)] = mattvec_acc(tr, Xj, Fjk, F.get((p, k), zeros6(tr)))
+            UD = [Uj[r] * Dj for r in range(6)]
+            Ia = [[None] * 6 for _ in range(6)]
+            for r in range(6):
+                for c in range(r, 6):
+                    val = tr.zero() if (r == s or c == s) else tr.fma(-UD[r], Uj[c], IAj[r][c])
+                    Ia[r][c] = val
+                    Ia[c][r] = val
+            Tm = [[tr.dot([(Ia[r][k], Xj[k][c]) for k in range(6)]) for c in range(6)] for r in range(6)]
+            IAp = IA_of(p)
+            for r in range(6):
+                for c in range(r, 6):
+                    val = tr.dot([(Xj[k][r], Tm[k][c]) for k in range(6)], init=IAp[r][c])
+                    IAp[r][c] = val
+                    IAp[c][r] = val
+            del IA[j]
+
+
+def minv_forward_lean(tr, spec, X_fwd, fetch, cols, on_final):
+    """Forward pass of the Minv recursion (_direct_minv, second loop) for the columns `cols` only -- the pass is independent per column,
+    so the waves of a block divide the columns -- from the published values of minv_backward_lean: fetch("U" | "D" | "M", j, i).
+    on_final(j, k, value): Minv[j][k] (k >= j, k in cols) has its final value; not called where the backward-pass value already is
+    the final one (base joints: the published slot is right as it stands)."""
+    n = spec.n
+    cols = sorted(cols)
+    tree_root = {}
+    for j in range(n):
+        tree_root[j] = j if spec.parent[j] == -1 else tree_root[spec.parent[j]]
+    roots = set(tree_root[k] for k in cols)
+    Fn = {}
+    with tr.mixed_region():
+        for j in range(n):
+            if tree_root[j] not in roots:
+                continue
+            mine = [k for k in cols if k >= j and tree_root[k] == tree_root[j]]
+            if not mine:
+                continue
+            p, s = spec.parent[j], spec.S_ind[j]
+            # joints off every path root -> column contribute only where F of the parent is non-zero: all joints j <= k of the tree do
+            need_X = (p != -1) or bool(spec.children[j])
+            Xj = X_fwd(j) if need_X else None
+            if p != -1:
+                UX = mattvec(tr, Xj, [fetch("U", j, r) for r in range(6)])
+                Dj = fetch("D", j, 0)
+            Mj = {}
+            for k in mine:
+                val = fetch("M", j, k) if k in spec.subtree[j] else tr.zero()
+                if p != -1 and (p, k) in Fn:
+                    val = val - Dj * tr.dot([(UX[r], Fn[(p, k)][r]) for r in range(6)])
+                    on_final(j, k, val)
+                elif p != -1 and k not in spec.subtree[j]:
+                    on_final(j, k, val)          # (a structural zero of the forward pass: written so that the slot holds a value)
+                Mj[k] = val
+            if not spec.children[j]:
+                continue
+            for k in mine:
+                Fjk = zeros6(tr)
+                Fjk[s] = Mj[k]
+                if p != -1 and (p, k) in Fn:
+                    Fjk = matvec_acc(tr, Xj, Fn[(p, k)], Fjk)
+                if all(x.is_zero() for x in Fjk):
+                    continue
+                Fn[(j, k)] = Fjk
 
 
 def minv_sym(Minv, r, c):
@@ -405,7 +523,8 @@ def minv_zero_pattern(spec):
     return [[not minv_sym(M, r, k).is_zero() for k in range(n)] for r in range(n)]
 
 
-def rnea_grad_columns(tr, spec, I, q, qd, trig, loader, emit_column, order=None, prefetch=3, xof=None, keep=()):
+def rnea_grad_columns(tr, spec, I, q, qd, trig, loader, emit_column, order=None, prefetch=3, xof=None, keep=(), xof_back=None,
+                      xa_first=False):
     """Column-serial analytical gradient of RNEA (same mathematics as rnea_grad / _test.py:229-488).
 
     Designed for robots whose gradient working set does not fit the register file (Atlas-30: 880 live values in the
@@ -415,6 +534,11 @@ def rnea_grad_columns(tr, spec, I, q, qd, trig, loader, emit_column, order=None,
     whole visit sequence is known at generation time, so the loads of visit i + `prefetch` are issued at the start of
     visit i (loader(kind, j) -> 6 fresh load nodes; kinds "v", "xa", "f").  For every column `emit_column(col, dc)`
     receives dc = {row: (d/dq value, d/dqd value)} for the structurally non-zero rows and emits what depends on it.
+
+    xof_back(j): X_j for the way BACK up the tree (child -> parent force transfer); None: the X used on the way down (alive across
+    the child's whole subtree, ~12 registers per level of the path).  xa_first: request X_j a_parent of the column's joint before
+    its v (the chain root -> joint is then traced joint by joint: X_j, a_j, v_j -- instead of all v first, all a after, which keeps
+    every X_j of the path alive in between).
     """
     n = spec.n
     cols = list(order if order is not None else range(n))
@@ -429,9 +553,13 @@ def rnea_grad_columns(tr, spec, I, q, qd, trig, loader, emit_column, order=None,
     def issue_upto(limit):
         while state["next"] < min(limit, len(plan)):
             col, j = plan[state["next"]]
-            vals = {"v": loader("v", j)}
-            if j == col:
+            vals = {}
+            if j == col and xa_first:
                 vals["xa"] = loader("xa", j)
+            vals["v"] = loader("v", j)
+            if j == col:
+                if not xa_first:
+                    vals["xa"] = loader("xa", j)
                 if spec.parent[j] != -1:
                     vals["f"] = loader("f", j)
             issued[(col, j)] = vals
@@ -482,7 +610,7 @@ def rnea_grad_columns(tr, spec, I, q, qd, trig, loader, emit_column, order=None,
                 dfs.append(t)
             for c in spec.children[j]:
                 dfc = visit(c, (dvq, dvqd), (daq, daqd))
-                Xch = Xof(c)
+                Xch = (xof_back or Xof)(c)
                 dfs = [mattvec_acc(tr, Xch, dfc[0], dfs[0]), mattvec_acc(tr, Xch, dfc[1], dfs[1])]
             if j == col and p != -1:
                 dfs[0] = vadd(dfs[0], fxS(tr, s, got["f"]))
@@ -493,7 +621,7 @@ def rnea_grad_columns(tr, spec, I, q, qd, trig, loader, emit_column, order=None,
         c = col
         while spec.parent[c] != -1:              # carry the column up through its ancestors
             k = spec.parent[c]
-            Xch = Xof(c)
+            Xch = (xof_back or Xof)(c)
             cur = [mattvec(tr, Xch, cur[0]), mattvec(tr, Xch, cur[1])]
             dc[k] = (cur[0][spec.S_ind[k]], cur[1][spec.S_ind[k]])
             c = k

@@ -175,6 +175,35 @@ class CoopSlots:
         self.hoist_cost = None
         self.hoist_max_columns = 4       # n parked values per column stay in registers across the barriers
 
+    lean = False            # see enable_lean()
+    itab = None
+
+    def enable_lean(self, spec):
+        """Register-lean cores for blocks whose waves PAIR UP on the SIMDs (8 waves per tile, <= 256 registers each; the 4-wave
+        kernel's waves own a SIMD and 464 registers).  What changes in the cores (core_gradient_recompute):
+          * sin q, cos q, qd (q of prismatic joints) live in a block-shared input table of the exchange region -- every wave writes the
+            same values before it reads any (DS operations of a wave execute in order; the other waves' writes are bit-identical) --
+            and are re-read where a joint is touched instead of staying in ~4n registers; qdd is re-read from the producers' slots;
+          * X_j is rebuilt for the way back up the tree instead of staying alive across the child's subtree (12 registers per level);
+          * the chain root -> column joint is traced joint by joint (X_j, a_j, v_j), the subtree's v, a are forgotten after the walk
+            that accumulates the column joint's force;
+          * no f table (its 41 KB are the staging regions of the four extra waves).
+        A wave's work is a list of HALF columns [(column, 0 = d/dq | 1 = d/dqd)]: the two halves of a column share nothing but v and
+        X, so they can run on different waves, each carrying half of the gradient state."""
+        n = spec.n
+        self.lean = True
+        self.f = {}
+        self.f_table = False
+        base = len(self.minv)
+        self.count = base + 2 * n               # c, qdd (one producer of qdd per row: no second share)
+        self.qdd2 = None
+        self.itab = {"s": [self.count + j for j in range(n)], "c": [self.count + n + j for j in range(n)],
+                     "qd": [self.count + 2 * n + j for j in range(n)], "u": [self.count + 3 * n + j for j in range(n)]}
+        self.count += 4 * n
+        if any(not t for t in spec.uses_trig):
+            self.itab["q"] = [self.count + j for j in range(n)]
+            self.count += n
+
     def hoisted_columns(self, role, cols):
         """The columns of `cols` whose d/dqd recursion this role runs ahead of the barriers: cheapest first while the budget lasts."""
         if not self.hoist_budget or role not in self.hoist_budget or not cols:
@@ -194,6 +223,171 @@ class CoopSlots:
 
 
 COOP_ROLES = ("producer", "producer2", "consumer_c", "consumer")
+
+
+class LeanRole:
+    """What ONE wave of a register-lean tile-cooperative block (CoopSlots.enable_lean, 8 waves per tile) does before its gradient
+    half-columns:
+
+        joints      phase 0: the joints whose sin q, cos q, qd, u this wave writes to the block's input table        -> barrier B0
+        minv_bwd    phase 1: joints (whole base-rooted trees) whose BACKWARD pass of the Minv recursion this wave runs, publishing
+                    U, 1/D and the backward-pass entries (alg.minv_backward_lean) -- once per tree, shared by every wave
+        c_roots     phase 1: base joints of the trees whose bias torques c = RNEA(q, qd, 0) this wave computes (depth first: only one
+                    root-to-leaf path of v, a, f alive) and publishes
+        hoist       phase 1: columns whose d/dqd recursion runs here, ahead of the barriers (n parked values per column)
+                                                                                                                      -> barrier B1
+        minv_cols   phase 2: the columns of Minv whose FORWARD pass this wave runs (alg.minv_forward_lean: independent per column,
+                    so all waves share it)                                                                            -> barrier B2
+        qdd_rows    phase 3: rows r of qdd = Minv_sym (u - c) this wave computes from the published Minv and c        -> barrier B3
+    Every wave executes the same four barriers."""
+
+    def __init__(self, name="consumer", joints=(), minv_bwd=(), minv_cols=(), c_roots=(), hoist=(), qdd_rows=(), minv_bwd_cols=None):
+        self.name, self.joints, self.minv_bwd, self.minv_cols = name, list(joints), list(minv_bwd), sorted(minv_cols)
+        self.minv_bwd_cols = None if minv_bwd_cols is None else sorted(minv_bwd_cols)     # (only these columns of the backward pass)
+        self.c_roots, self.hoist, self.qdd_rows = list(c_roots), list(hoist), list(qdd_rows)
+
+    def __repr__(self):
+        return "LeanRole(%s: table %s, Minv backward pass of %s%s, c of trees %s, parked %s, Minv forward columns %s, qdd rows %s)" % (
+            self.name, self.joints, self.minv_bwd, "" if self.minv_bwd_cols is None else " columns %s" % self.minv_bwd_cols,
+            self.c_roots, self.hoist, self.minv_cols, self.qdd_rows)
+
+
+LEAN_BARRIERS = 4
+FWD_BIAS = (0.0,)       # (planner: extra cost charged to wave w's forward-pass share; one entry = the same for every wave)
+LEAN_WAVES = 8
+LEAN_YOUNGER_SPEED = 1.0        # weight of the waves dispatched second when the gradient half-columns are dealt out.  Issue-bound code
+                                # gives the younger wave of a SIMD 0.57-0.67 of the older one's pace (profiles/r03/two_waves_per_simd.md);
+                                # these cores wait on LDS and on dependent chains (6.3 cycles per instruction alone), and equal shares
+                                # measured best: K = 16384 57.5 us (0.6), 55.3 (0.8), 54.2 (1.0), 56.3 (1.25) -- profiles/r04/lean_probe_2.txt
+LEAN_FLUSH_SLOTS = 150          # issue slots one half-column flush (n LDS writes, a wave sync, the paired reads and stores) costs
+
+
+def lean_arith(tr, start=1, stop=None):
+    """Arithmetic instructions + LDS reads of the live part of a trace between two node positions."""
+    live = tr.live_nodes()
+    stop = len(tr.nodes) if stop is None else stop
+    return sum(1 for k in range(start, stop) if live[k] and tr.nodes[k][0] in ("fma", "mul", "add", "rcp", "in"))
+
+
+def lean_barriers(tr):
+    return [pos for (dst, _), pos in zip(tr.outputs, tr.out_pos) if dst == "barrier"]
+
+
+def lean_plan(spec, waves=LEAN_WAVES, max_parked=3, younger_speed=None):
+    """Who does what in a register-lean block of `waves` wavefronts (two per SIMD): returns (slots, [(LeanRole, [(column, half)])]).
+
+    Phase 0 (input table): joints dealt round-robin.  Phase 1: the BACKWARD pass of the Minv recursion once per base-rooted tree -- the
+    largest tree on wave 0, the others on wave 1, which also computes their bias torques; wave 2 computes the largest tree's bias
+    torques.  Waves 0-3 are dispatched first (the OLDER wave of each SIMD, which keeps the lone-wave pace) and take these roles;
+    the waves that are free run d/dqd recursions ahead of the barrier (parked, at most `max_parked` columns of n values each).
+    Phase 2: the FORWARD pass, independent per column, divided over all waves in contiguous runs of balanced cost.  Phase 3: qdd rows
+    round-robin.  Gradient half-columns: longest-processing-time placement on traced per-item costs, a younger wave's items
+    weighted by 1 / younger_speed (default LEAN_YOUNGER_SPEED)."""
+    from .model import base_trees
+    n = spec.n
+    slots = CoopSlots(spec)
+    slots.enable_lean(spec)
+    trees = sorted(base_trees(spec), key=lambda t: -t[1])
+    big = list(range(trees[0][0], trees[0][0] + trees[0][1]))
+    rest = [j for (f, m) in trees[1:] for j in range(f, f + m)]
+    rest_roots = [f for (f, m) in trees[1:]]
+
+    def probe(role, items):
+        return core_gradient_recompute(spec, "fd", cols=items, coop=(role, slots))
+    # the largest tree's backward pass on two waves: both run the articulated-inertia chain (U, 1/D), each the F recursions of its
+    # share of the columns -- the cut that balances the two (the early columns walk further up the tree)
+    def bwd_cost(cols_):
+        tr = probe(LeanRole("minv_backward", minv_bwd=big, minv_bwd_cols=cols_), [(n - 1, 1)])
+        b = lean_barriers(tr)
+        return lean_arith(tr, b[0], b[1])
+    cut_b = min(range(big[0] + 1, big[-1] + 1), key=lambda c_: max(bwd_cost([k for k in big if k < c_]), bwd_cost([k for k in big if k >= c_])))
+    roles = [LeanRole("minv_backward_a", minv_bwd=big, minv_bwd_cols=[k for k in big if k < cut_b]),
+             LeanRole("minv_backward_b", minv_bwd=big, minv_bwd_cols=[k for k in big if k >= cut_b]),
+             LeanRole("minv_backward+c", minv_bwd=rest, c_roots=rest_roots) if rest else LeanRole("consumer"),
+             LeanRole("c", c_roots=[big[0]])]
+    roles += [LeanRole("consumer") for _ in range(waves - len(roles))]
+    # forward pass: a wave that finishes columns a..b-1 walks every joint j < b of their trees (fixed cost per joint: U, 1/D, X_j, X_j^T U)
+    # and pays per (joint, column >= joint) pair; contiguous runs share the joints.  Minimise the largest run (dynamic programme).
+    tree_of = {}
+    for (f, m) in base_trees(spec):
+        for j in range(f, f + m):
+            tree_of[j] = f
+    PER_JOINT, PER_PAIR = 45.0, 16.0
+
+    def run_cost(a, b):
+        cost_, seen = 0.0, set()
+        for k in range(a, b):
+            for j in range(tree_of[k], k + 1):
+                if j not in seen:
+                    seen.add(j)
+                    cost_ += PER_JOINT
+                cost_ += PER_PAIR
+        return cost_
+    INF = float("inf")
+    best = [[INF] * (n + 1) for _ in range(waves + 1)]
+    cut = [[0] * (n + 1) for _ in range(waves + 1)]
+    best[0][0] = 0.0
+    for w in range(1, waves + 1):
+        for e in range(w, n + 1):
+            for b_ in range(w - 1, e):
+                if best[w - 1][b_] < INF:
+                    c_ = max(best[w - 1][b_], run_cost(b_, e) + FWD_BIAS[min(w - 1, len(FWD_BIAS) - 1)])
+                    if c_ < best[w][e]:
+                        best[w][e], cut[w][e] = c_, b_
+    e = n
+    for w in range(waves, 0, -1):
+        roles[w - 1].minv_cols = list(range(cut[w][e], e))
+        e = cut[w][e]
+    for w, role in enumerate(roles):
+        role.joints = [j for j in range(n) if j % waves == w]
+        role.qdd_rows = [j for j in range(n) if j % waves == w]
+
+    def phase_costs(role):
+        tr = probe(role, [(n - 1, 1)])
+        b = lean_barriers(tr)
+        return lean_arith(tr, b[0], b[1]), lean_arith(tr, b[1], b[2])
+    ph = [phase_costs(r) for r in roles]
+    t_b1 = max(p1 for (p1, _) in ph)
+    # per-item costs: the recursion (what parking moves ahead of the barrier) and the whole item
+    cost, rec = {}, {}
+    for c_ in range(n):
+        for h in (0, 1):
+            tr = probe(LeanRole("consumer"), [(c_, h)])
+            b = lean_barriers(tr)
+            cost[(c_, h)] = lean_arith(tr, b[-1]) + LEAN_FLUSH_SLOTS
+        trp = probe(LeanRole("consumer", hoist=[c_]), [(c_, 1)])
+        b = lean_barriers(trp)
+        rec[c_] = lean_arith(trp, b[0], b[1])
+    speed = [1.0 if w < waves // 2 else (LEAN_YOUNGER_SPEED if younger_speed is None else younger_speed) for w in range(waves)]
+    load = [0.0] * waves
+    items = [[] for _ in range(waves)]
+    parked = [[] for _ in range(waves)]
+    slack = [t_b1 - ph[w][0] for w in range(waves)]
+    for it in sorted(cost, key=lambda it: -cost[it]):
+        if cost[it] <= LEAN_FLUSH_SLOTS:
+            continue                                   # structurally zero half-column: placed last, wherever it is cheapest
+
+        def finish(w):
+            c_, h = it
+            gain = rec[c_] if (h == 1 and len(parked[w]) < max_parked and rec[c_] <= slack[w]) else 0
+            return (load[w] + cost[it] - gain) / speed[w], gain
+        w = min(range(waves), key=lambda w: finish(w)[0])
+        gain = finish(w)[1]
+        if gain:
+            parked[w].append(it[0])
+            slack[w] -= gain
+        load[w] += cost[it] - gain
+        items[w].append(it)
+    for it in sorted(cost):
+        if cost[it] <= LEAN_FLUSH_SLOTS:
+            w = min(range(waves), key=lambda w: (load[w] + cost[it]) / speed[w])
+            load[w] += cost[it]
+            items[w].append(it)
+    for w, role in enumerate(roles):
+        role.hoist = sorted(parked[w])
+    plan = [(roles[w], sorted(items[w])) for w in range(waves)]
+    slots.lean_model = dict(phase1=[p1 for (p1, _) in ph], phase2=[p2 for (_, p2) in ph], t_b1=t_b1, post=[load[w] / speed[w] for w in range(waves)])
+    return slots, plan
 
 
 def _coop_prologue(tr, spec, slots, role, X, I, qd, u, g, demand_order=True, pre_barrier=None):
@@ -524,13 +718,18 @@ def optimal_column_sets(spec, S, full):
     return parts, best[0]
 
 
-def optimal_half_column_sets(spec, S, full, restarts=20):
+def optimal_half_column_sets(spec, S, full, restarts=20, weights=None, per_value=0.0):
     """Partition of the 2n HALF columns -- (column, d/dq) and (column, d/dqd) are separate items: the two halves of a gradient column
     share nothing but the prefix -- into S groups minimising the largest group's arithmetic (cost of a group = live arithmetic nodes
     of `full` when only its outputs are kept, as in optimal_column_sets).  2n items are too many for the exhaustive search; this is
     longest-processing-time placement followed by single moves and swaps out of the heaviest group, from `restarts` deterministic
     perturbed orders.  iiwa-7 forward-dynamics gradient, S = 4: 2771 operations against 2937 for whole columns.
-    Returns (parts, worst) with parts = [(d/dq columns, d/dqd columns)] sorted by their first column."""
+    per_value: issue slots charged per OUTPUT value of a group (staging write, flush read, store: the stamped 4-way kernel's groups took
+    15.3 / 15.3 / 13.9 / 13.9 k cycles for 2804 / 2805 / 2700 / 2718 operations and 35 / 35 / 14 / 14 values -- ~43 cycles = ~10 slots per
+    value, profiles/r03/phase_stamps_iiwa7_split4_16384.txt).  weights[g]: the cost of group g counts weights[g]-fold -- groups that run
+    as the YOUNGER wave of a SIMD get what the older one leaves (asymmetric 8-way split: four heavy groups dispatched first, four
+    light ones behind them); groups keep their index then (no sorting).
+    Returns (parts, worst) with parts = [(d/dq columns, d/dqd columns)] sorted by their first column (unweighted) / in group order."""
     import random
     n = spec.n
     roots = {}
@@ -555,14 +754,17 @@ def optimal_half_column_sets(spec, S, full, restarts=20):
         bits[item] = mask
     memo = {}
 
-    def cost(group):
+    def cost0(group):
         key = frozenset(group)
         if key not in memo:
             m = 0
             for it in key:
                 m |= bits[it]
-            memo[key] = bin(m).count("1")
+            memo[key] = bin(m).count("1") + per_value * n * len(key)
         return memo[key]
+    wts = [1.0] * S if weights is None else list(weights)
+    gcost = lambda k, group: (cost0(group) * wts[k]) if group else 0.0
+    cost = cost0
     items = sorted(bits)
     best = None
     for trial in range(restarts):
@@ -570,12 +772,12 @@ def optimal_half_column_sets(spec, S, full, restarts=20):
         order = sorted(items, key=lambda it: -cost([it]) + rng.random() * (0 if trial == 0 else 300))
         groups = [[] for _ in range(S)]
         for it in order:
-            k = min(range(S), key=lambda k: (cost(groups[k] + [it]), k))
+            k = min(range(S), key=lambda k: (gcost(k, groups[k] + [it]), k))
             groups[k].append(it)
         improved = True
         while improved:
             improved = False
-            cs = [cost(gp) for gp in groups]
+            cs = [gcost(k, gp) for k, gp in enumerate(groups)]
             w = max(range(S), key=lambda i: cs[i])
             moves = []
             for it in groups[w]:
@@ -589,14 +791,15 @@ def optimal_half_column_sets(spec, S, full, restarts=20):
                 ng[w].remove(it); ng[k].append(it)
                 if jt is not None:
                     ng[k].remove(jt); ng[w].append(jt)
-                if all(ng) and max(cost(gp) for gp in ng) < cs[w]:
+                if all(ng) and max(gcost(k, gp) for k, gp in enumerate(ng)) < cs[w]:
                     groups, improved = ng, True
                     break
-        worst = max(cost(gp) for gp in groups)
+        worst = max(gcost(k, gp) for k, gp in enumerate(groups))
         if all(groups) and (best is None or worst < best[0]):
             best = (worst, [sorted(gp) for gp in groups])
     parts = [(sorted(c for (c, h) in gp if h == 0), sorted(c for (c, h) in gp if h == 1)) for gp in best[1]]
-    parts.sort(key=lambda p: min(p[0] + p[1]))
+    if weights is None:
+        parts.sort(key=lambda p: min(p[0] + p[1]))
     return parts, best[0]
 
 
@@ -876,6 +1079,15 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
     trig = alg.trig_from_q(tr, spec, q)
     I = alg.build_I(tr, spec)
     Minv = None
+    lean = coop is not None and coop[1].lean
+    itab = coop[1].itab if lean else None
+    want = None             # lean cores: cols = [(column, half)] -> {column: halves to emit}; tr.run_bases = row offset of each emitted run
+    if coop is not None and cols and isinstance(cols[0], tuple):
+        want = {}
+        for (c_, h_) in cols:
+            want.setdefault(c_, set()).add(h_)
+        cols = sorted(want)
+    tr.run_bases = []
     if coop is not None:
         assert kind == "fd" and not use_qdd_minv and not table and rollout is None
         role, slots = coop
@@ -941,6 +1153,16 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
             qd[j] = tr.tab_get(slot["qd"] + j)
             if qdd is not None:
                 qdd[j] = tr.tab_get(slot["qdd"] + j)
+        elif ("t", j) not in memo and itab is not None:
+            # block-shared input table (CoopSlots.enable_lean): a fresh LDS read per touch, nothing of the inputs stays in registers
+            memo[("t", j)] = True
+            if trig[j] is not None:
+                trig[j] = (tr.xch_get(itab["s"][j]), tr.xch_get(itab["c"][j]))
+            else:
+                q[j] = tr.xch_get(itab["q"][j])
+            qd[j] = tr.xch_get(itab["qd"][j])
+            if qdd is not None:
+                qdd[j] = tr.xch_get(coop[1].qdd[j])
         elif ("t", j) not in memo:
             memo[("t", j)] = True
             q[j] = tr.launder(q[j])
@@ -955,6 +1177,13 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
             touch(j)
             memo[("X", j)] = alg.build_X_joint(tr, spec, j, q[j], trig[j])
         return memo[("X", j)]
+
+    def Xof_back(j):
+        # lean cores: X_j for the force transfer child -> parent is REBUILT (from re-read sin / cos) instead of staying alive across
+        # the child's whole subtree
+        memo.pop(("X", j), None)
+        memo.pop(("t", j), None)
+        return Xof(j)
 
     def v_of(j):
         if ("v", j) not in memo:
@@ -987,7 +1216,7 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
             memo[("a", j)] = a
         return memo[("a", j)]
 
-    ftab = {"on": False, "done": set()}     # tile-cooperative cores: f of the wave's own finished columns lives in LDS (CoopSlots.f)
+    ftab = {"on": False, "done": set(), "hook": None}     # tile-cooperative cores: f of the wave's own finished columns lives in LDS (CoopSlots.f)
 
     def facc(j):
         if ("f", j) not in memo and ftab["on"] and j in ftab["done"]:
@@ -996,8 +1225,14 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
             v = v_of(j)
             f = alg.vadd(alg.matvec(tr, I[j], a_of(j)), alg.fxv(tr, v, alg.matvec(tr, I[j], v)))
             for ch in spec.children[j]:
-                f = alg.mattvec_acc(tr, Xof(ch), facc(ch), f)
+                if lean:
+                    fch = facc(ch)
+                    f = alg.mattvec_acc(tr, Xof_back(ch), fch, f)
+                else:
+                    f = alg.mattvec_acc(tr, Xof(ch), facc(ch), f)
             memo[("f", j)] = f
+            if ftab["hook"] is not None:
+                ftab["hook"](j, f)
         return memo[("f", j)]
 
     def loader(kind_, j):
@@ -1013,6 +1248,15 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
             for key in [key for key in memo if key[0] == "t"]:       # reload inputs for what follows
                 del memo[key]
             for key in [key for key in memo if key[0] in ("X", "v", "xa", "a")]:
+                del memo[key]
+            return f
+        if kind_ == "f" and lean:
+            # the walk that accumulates the column joint's force visits the joint's whole subtree; what it computed on the way (v, a, X
+            # of every joint below) is forgotten -- the gradient walk recomputes v where it needs it -- otherwise 6-12 values per subtree
+            # joint stay alive from here to their visit (18 joints below the torso: 100+ registers)
+            f = facc(j)
+            below = set(spec.subtree[j]) - {j}
+            for key in [key for key in memo if key[1] in below]:
                 del memo[key]
             return f
         if kind_ == "f" and ftab["on"]:
@@ -1051,8 +1295,19 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
         if coop is not None:
             # every upper-triangle entry fetched once per column from the exchange region (4 multiply-adds per LDS read)
             dqd_half = saved_dqd.pop(col, None) or {k: dc[k][1] for k in rows}       # (computed ahead of the barriers when parked)
+            halves = want[col] if want is not None else (0, 1)
+            none = {k: tr.zero() for k in rows}
             lo, hi = alg.sym_minv_times_columns(tr, spec, lambda r, k: minv_entry(r, k),
-                                                {k: dc[k][0] for k in rows}, {k: dqd_half[k] for k in rows})
+                                                {k: dc[k][0] for k in rows} if 0 in halves else none,
+                                                {k: dqd_half[k] for k in rows} if 1 in halves else none)
+            if want is not None:
+                # half-column runs in emission order: run k of the core (n values) goes to row offset tr.run_bases[k] (grid_out_runs)
+                for h in sorted(halves):
+                    k_run = len(tr.run_bases)
+                    tr.run_bases.append(n * col + h * n * n)
+                    for r in range(n):
+                        tr.out(n * k_run + r, (lo, hi)[h][r])
+                return
             for r in range(n):
                 tr.out(lo_base(col) + r, lo[r])
             for r in range(n):
@@ -1082,7 +1337,10 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
         # phases 1 and 2 of the block (_coop_prologue).  A consumer fills its idle time with the d/dqd recursions of some of its
         # columns (CoopSlots.hoisted_columns): they need neither qdd nor Minv; the n values per column stay in registers until
         # the column's products after the second barrier.
-        hoist = slots.hoisted_columns(role, list(cols)) if role in ("consumer", "consumer_c") else []
+        if lean:
+            hoist = [c_ for c_ in role.hoist if c_ in cols and (want is None or 1 in want[c_])]
+        else:
+            hoist = slots.hoisted_columns(role, list(cols)) if role in ("consumer", "consumer_c") else []
 
         def pre_barrier():
             def capture(col, dc):
@@ -1090,17 +1348,77 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
                 saved_dqd[col] = {k: dc[k][1] for k in dc}
                 for v in saved_dqd[col].values():
                     tr.anchor(v)
-            alg.rnea_grad_columns(tr, spec, I, q, qd, trig, loader, capture, order=hoist, prefetch=0, xof=Xof, keep=keep)
+            alg.rnea_grad_columns(tr, spec, I, q, qd, trig, loader, capture, order=hoist, prefetch=0, xof=Xof, keep=keep,
+                                  xof_back=Xof_back if lean else None, xa_first=lean)
         mark = tr.cse_mark()
         u = [tr.inp("in.u(%d)" % j) for j in range(n)]
-        X = alg.build_X(tr, spec, q, trig)
-        qdd = list(_coop_prologue(tr, spec, slots, role, X, I, qd, u, g, demand_order=False, pre_barrier=pre_barrier if hoist else None))
+        if lean:
+            assert not tr.mixed, "the register-lean cores exist in the fp32 arithmetic only"
+            # ---- phase 0: this wave's share of the block's input table, then B0 (everything below reads inputs through touch())
+            for j in role.joints:
+                if trig[j] is not None:
+                    tr.xch_put(itab["s"][j], trig[j][0])
+                    tr.xch_put(itab["c"][j], trig[j][1])
+                else:
+                    tr.xch_put(itab["q"][j], q[j])
+                tr.xch_put(itab["qd"][j], qd[j])
+                tr.xch_put(itab["u"][j], u[j])
+            tr.barrier()
+            # ---- phase 1: backward pass of the Minv recursion (once per tree) | bias torques | parked d/dqd recursions, then B1
+            def scratch(j, i):          # U_j (6) and 1/D_j of the backward pass: LDS words BELOW the exchange region -- the waves'
+                return -(1 + 7 * j + i)   # staging regions, which nobody uses before the first output flush (after the last barrier)
+
+            def where(kind_, j, i):
+                return slots.minv[(j, i)] if kind_ == "M" else scratch(j, 6 if kind_ == "D" else i)
+            if role.minv_bwd:
+                alg.minv_backward_lean(tr, spec, I, Xof_back, lambda kind_, j, i, val: tr.xch_put(where(kind_, j, i), val), role.minv_bwd,
+                                       cols=role.minv_bwd_cols)
+                memo.clear()
+            if role.c_roots:
+                def publish_c(j, f):
+                    tr.xch_put(slots.c[j], f[spec.S_ind[j]] + qd[j] * spec.damping[j])
+                ftab["hook"] = publish_c
+                for root in role.c_roots:
+                    facc(root)
+                ftab["hook"] = None
+                memo.clear()
+            if hoist:
+                pre_barrier()
+            tr.barrier()
+            # ---- phase 2: forward pass of the Minv recursion for this wave's columns, then B2
+            if role.minv_cols:
+                def on_final(j, k, val):
+                    if slots.minv.get((j, k)) is not None:
+                        tr.xch_put(slots.minv[(j, k)], val)
+                alg.minv_forward_lean(tr, spec, Xof_back, lambda kind_, j, i: tr.xch_get(where(kind_, j, i)), role.minv_cols, on_final)
+                memo.clear()
+            tr.barrier()
+            # ---- phase 3: rows of qdd = Minv_sym (u - c) from the published Minv and c, then B3
+            if role.qdd_rows:
+                umc = {}
+                for r in role.qdd_rows:
+                    terms = []
+                    for k in range(n):
+                        m = slots.entry(tr, r, k)
+                        if m is None:
+                            continue
+                        if k not in umc:
+                            umc[k] = tr.xch_get(itab["u"][k]) - tr.xch_get(slots.c[k])
+                        terms.append((m, umc[k]))
+                    tr.xch_put(slots.qdd[r], tr.dot(terms))
+            tr.barrier()
+            qdd = [tr.zero()] * n       # (placeholders: touch() reads the published qdd of every joint it visits)
+        else:
+            X = alg.build_X(tr, spec, q, trig)
+            qdd = list(_coop_prologue(tr, spec, slots, role, X, I, list(qd), u, g, demand_order=False, pre_barrier=pre_barrier if hoist else None))
         tr.fence()
-        tr.cse_release(mark, keep=[t.ref for pair in trig if pair is not None for t in pair] + [v.ref for d in saved_dqd.values() for v in d.values() if not isinstance(v.ref, float)])
+        kept_trig = [] if itab is not None else [t.ref for pair in trig if pair is not None for t in pair]
+        tr.cse_release(mark, keep=kept_trig + [v.ref for d in saved_dqd.values() for v in d.values() if not isinstance(v.ref, float)])
         memo.clear()
         # the parked columns first (their registers are freed early), and within both runs the deepest first: a column's accumulated
         # force then finds its children's in the f table (DFS pre-order ids: children have larger ids)
         order = sorted(hoist, reverse=True) + sorted((c for c in cols if c not in hoist), reverse=True)
         ftab["on"] = bool(slots.f_table)
-    alg.rnea_grad_columns(tr, spec, I, q, qd, trig, loader, emit_column, order=order, prefetch=0, xof=Xof, keep=keep)
+    alg.rnea_grad_columns(tr, spec, I, q, qd, trig, loader, emit_column, order=order, prefetch=0, xof=Xof, keep=keep,
+                          xof_back=Xof_back if lean else None, xa_first=lean)
     return tr

@@ -554,7 +554,7 @@ class Tracer:
                 return ("t%d" % nl[1]) if l > 0 else ("-t%d" % nl[1])
         return "C2{%s, %s}" % (self._opnd(l), self._opnd(h))
 
-    def emit(self, indent="    ", order="demand", store=None, after_store=None, fence_every=0, fence_stmt="GRID_SCHED_FENCE();"):
+    def emit(self, indent="    ", order="demand", store=None, after_store=None, fence_every=0, fence_stmt="GRID_SCHED_FENCE();", read_ahead=0):
         """C++ statements (compute type ``C``, storage type ``T``) for all live nodes + output stores.
 
         order="demand": outputs are visited in order and each pulls in (post-order) whatever it still
@@ -633,6 +633,35 @@ class Tracer:
             # nodes in trace order; every store where the algorithm recorded it; explicit fences honoured
             events = sorted([(pos, 0, i) for i, pos in enumerate(self.out_pos)] + [(pos, 1, -1) for pos in self.fences])
             ev = 0
+            # read_ahead = L > 0: reads of the block's LDS regions (exchange slots, parked values) are issued L live nodes AHEAD of the
+            # place the algorithm asked for them -- an LDS round trip is 64-128 cycles, a lone or older wave issues an instruction per
+            # ~4, and the scheduling fences keep hipcc from hoisting a read out of its region by itself -- but never above a block
+            # barrier nor above this wave's own write to the same slot.  Same values, earlier requests.
+            early = {}
+            if read_ahead > 0:
+                live_idx = [k for k in range(1, len(self.nodes)) if live[k]]
+                rank = {k: i for i, k in enumerate(live_idx)}
+                floor_all = 1                      # after the latest barrier so far
+                last_put = {}                      # slot -> position of this wave's latest write to it
+                outs_sorted = sorted(zip(self.out_pos, range(len(self.outputs))))
+                oi = 0
+                for k in live_idx:
+                    while oi < len(outs_sorted) and outs_sorted[oi][0] <= k:
+                        pos, i = outs_sorted[oi]
+                        dst = self.outputs[i][0]
+                        if dst == "barrier":
+                            floor_all = pos
+                        elif isinstance(dst, str) and (dst.startswith("tab:") or dst.startswith("xch:")):
+                            last_put[dst.split(":")[1]] = pos
+                        oi += 1
+                    op, a = self.nodes[k][0], self.nodes[k][1]
+                    if op == "in" and isinstance(a, str) and (a.startswith("in.xch_get(") or a.startswith("in.tab_get(")):
+                        slot = a[a.index("(") + 1:a.index(")")]
+                        lo = max(floor_all, last_put.get(slot, 1))
+                        target = live_idx[max(0, rank[k] - read_ahead)]
+                        target = max(target, lo)
+                        if target < k:
+                            early.setdefault(target, []).append(k)
             for k in range(1, len(self.nodes) + 1):
                 while ev < len(events) and events[ev][0] <= k:
                     _, kind, i = events[ev]
@@ -646,6 +675,9 @@ class Tracer:
                         extra = after_store(i)
                         if extra:
                             lines.append(indent + extra)
+                for kk in early.get(k, ()):
+                    if not emitted[kk]:
+                        emit_node(kk)
                 if k < len(self.nodes) and live[k] and not emitted[k]:
                     emit_node(k)
             return lines
@@ -669,6 +701,31 @@ class Tracer:
                 if extra:
                     lines.append(indent + extra)
         return lines
+
+    def max_live(self):
+        """Most values alive at once when the live part of the trace is emitted in creation order (the order of the column-serial and
+        tile-cooperative cores): a lower bound of the registers the straight-line body needs -- hipcc adds addresses, temporaries of
+        its own scheduling and, above the budget, spills.  Returns (count, node position of the maximum)."""
+        live = self.live_nodes()
+        last = {}
+        for k in range(1, len(self.nodes)):
+            if live[k]:
+                for d in self._deps(k):
+                    last[d] = k
+        for (dst, r), pos in zip(self.outputs, self.out_pos):
+            if not isinstance(r, float):
+                last[abs(r)] = max(last.get(abs(r), 0), pos)
+        ev = [0] * (len(self.nodes) + 2)
+        for k in range(1, len(self.nodes)):
+            if live[k] and self.nodes[k][0] != "lnd":
+                ev[k] += 1
+                ev[max(last.get(k, k), k) + 1] -= 1
+        cur = mx = where = 0
+        for i, e in enumerate(ev):
+            cur += e
+            if cur > mx:
+                mx, where = cur, i
+        return mx, where
 
     def _store_type(self, r):
         """An output is converted to the storage type T once, from whatever type its node has."""

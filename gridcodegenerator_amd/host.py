@@ -239,15 +239,20 @@ KERNARG_PRELOAD = ["-mllvm", "-amdgpu-kernarg-preload-count=16"]
 def generate_header(robot, path, namespace, **gen_kwargs):
     """Run the generator for ``robot`` and move ``<namespace>.hip.h`` (written to the CWD, as the
     reference writes grid.cuh to the CWD, GRiDCodeGenerator.py:308) to ``path``."""
+    import shutil
+    import tempfile
     gen = GRiDCodeGenerator(robot, FILE_NAMESPACE=namespace, **gen_kwargs)
     cwd = os.getcwd()
     os.makedirs(os.path.dirname(path), exist_ok=True)
-    os.chdir(os.path.dirname(path))
+    # a directory of its own: variants that share a namespace (OBJECT_CACHE_BASE) write the same file name, possibly at the same time
+    work = tempfile.mkdtemp(prefix=".gen_", dir=os.path.dirname(path))
+    os.chdir(work)
     try:
         gen.gen_all_code()
-        os.replace(gen.output_file_name(), path)
+        os.replace(os.path.join(work, gen.output_file_name()), path)
     finally:
         os.chdir(cwd)
+        shutil.rmtree(work, ignore_errors=True)
     return gen
 
 
@@ -265,8 +270,32 @@ def build_library(robot_name, precision="fp32", force=False, verbose=False, extr
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
+# Experiment variants of a built-in robot (same model, other generator options, registered under another name: tools/lean_variants.py,
+# tests/regression_variants.py) may share the BASE robot's object cache: the variant's header then uses the base's namespace and its
+# kernel translation units the base's defines, so every kernel whose slice of the header is unchanged is a cache hit and only the
+# kernels under study are compiled (an Atlas-30 library is 25 kernels and 15-35 minutes from scratch).  {variant name: base name}
+OBJECT_CACHE_BASE = {}
+
 # generator options used when a built-in robot is built without explicit options (tests rely on these)
 DEFAULT_GEN_KWARGS = {"mixed5": {"pipeline": True, "grad_schedule": "recompute", "experimental": {"grad_table": True, "split_sets": True}}}   # the small test robot exercises the two-pass kernels and the recomputing (LDS table) schedule, prismatic joints included
+
+
+def register_variant(name, base, share_objects=False, **gen_kwargs):
+    """The robot `base` once more under `name`, built with other generator options (on top of the base's defaults): a library of its
+    own, libgrid_<name>_<precision>.so.  share_objects: reuse the base library's kernel objects where the generated text agrees
+    (OBJECT_CACHE_BASE).  Idempotent."""
+    from . import robots
+    if name not in robots.REGISTERED_ROBOTS:
+        robots.register_robot(name, lambda: robots.get_robot(base))
+    DEFAULT_GEN_KWARGS[name] = dict(DEFAULT_GEN_KWARGS.get(base, {}), **gen_kwargs)
+    if share_objects:
+        OBJECT_CACHE_BASE[name] = base
+    return name
+
+
+# the prismatic test robot with the REFERENCE's gradient seed (motion cross product, _test.py:311,437): its HIP gradients are held to the
+# reference's own golden numbers (tests/test_gpu_parity.py::test_golden_fixtures); the shipped default stays "corrected"
+REFERENCE_GRADIENT_VARIANT = ("mixed5_refgrad", "mixed5")
 
 
 def _build_library_locked(robot_name, precision, force, verbose, extra_flags, gen_kwargs):
@@ -299,13 +328,19 @@ def _build_library_locked(robot_name, precision, force, verbose, extra_flags, ge
             if fh.read().strip() == fp:
                 return p["lib"]
     os.makedirs(BUILD_DIR, exist_ok=True)
-    ns = "grid_" + robot_name
+    cache_base = OBJECT_CACHE_BASE.get(robot_name)
+    ns = "grid_" + (cache_base or robot_name)
     gen = generate_header(robot_obj, p["header"], ns, precision=precision, **gen_kwargs)
     # one translation unit per kernel + the C-ABI unit, compiled in parallel, then linked
     common = [_hipcc()] + [f for f in flags if f != "-shared"] + [
-        "-c", "-DGRID_HEADER=\"%s\"" % p["header"], "-DGRID_NS=" + ns, "-DGRID_ROBOT_NAME=\"%s\"" % robot_name,
+        "-c", "-DGRID_HEADER=\"%s\"" % p["header"], "-DGRID_NS=" + ns, "-DGRID_ROBOT_NAME=\"%s\"" % (cache_base or robot_name),
         "-Rpass-analysis=kernel-resource-usage"]
     objdir = os.path.join(BUILD_DIR, "obj_" + p["tag"])
+    if cache_base and not os.path.isdir(objdir):
+        import shutil
+        src_dir = os.path.join(BUILD_DIR, "obj_" + library_paths(cache_base, precision)["tag"])
+        if os.path.isdir(src_dir):
+            shutil.copytree(src_dir, objdir)
     os.makedirs(objdir, exist_ok=True)
     jobs = [("capi", common + ["-DGRID_EXTERN_KERNELS", CSRC, "-o", os.path.join(objdir, "capi.o")])]
     for k in range(len(gen.kernel_instances)):
@@ -453,6 +488,11 @@ def build_single_timing_harness(robot_name, precision="fp32", force=False):
                 return out
     cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O1", "-ffp-contract=off", "-std=c++17"] + KERNARG_PRELOAD + ["-DGRID_HEADER=\"%s\"" % p["header"],
            "-DGRID_NS=grid_" + robot_name, SINGLE_TIMING_SRC, "-o", out + ".tmp"]
+    if get_robot(robot_name).get_num_joints() > 12:
+        # large robots: the library's kernels are linked in (minutes each to compile a second time); only the latency twins are built
+        # here, and the forward-dynamics gradient is compared norm-wise (mode 0 dispatches the tile-cooperative kernel)
+        lib = library_paths(robot_name, precision)["lib"]
+        cmd = cmd[:-2] + ["-DGRID_EXTERN_KERNELS", "-DGRID_ST_REL_TOL=2e-5", "-L" + BUILD_DIR, "-l" + os.path.basename(lib)[3:-3], "-Wl,-rpath,$ORIGIN"] + cmd[-2:]
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if proc.returncode != 0:
         raise GridLibraryError("hipcc failed for the single-timing harness of %s:\n%s" % (robot_name, proc.stdout[-4000:]))
@@ -500,6 +540,8 @@ CAPI_SIGNATURES = [
     ("grid_set_coop", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     ("grid_get_coop", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     ("grid_kernel_attributes_coop", ctypes.c_int, [ctypes.c_int, _c_int_p]),
+    ("grid_lean_available", ctypes.c_int, [ctypes.c_int]),
+    ("grid_kernel_attributes_lean", ctypes.c_int, [ctypes.c_int, _c_int_p]),
     ("grid_wave_available", ctypes.c_int, [ctypes.c_int]),
     ("grid_set_wave", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     ("grid_get_wave", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
@@ -556,6 +598,8 @@ class GridLibrary:
         out = (ctypes.c_int * 4)()
         if wave:
             self.check(self.lib.grid_kernel_attributes_wave(alg, out), "grid_kernel_attributes_wave")
+        elif coop == 2:       # the register-lean 8-wave variant (grid_get_coop's numbering)
+            self.check(self.lib.grid_kernel_attributes_lean(alg, out), "grid_kernel_attributes_lean")
         elif coop:
             self.check(self.lib.grid_kernel_attributes_coop(alg, out), "grid_kernel_attributes_coop")
         elif split > 1:
@@ -720,11 +764,16 @@ class GridHandle:
         self.L.check(self.L.lib.grid_set_split(self._h, alg, int(split)), "grid_set_split")
 
     def set_coop(self, alg, mode):
-        """Tile-cooperative kernel: 0 = automatic (default), 1 = never, 2 = always."""
+        """Tile-cooperative kernel: 0 = automatic (default), 1 = never, 2 = always (4 waves per tile), 3 = always its register-lean
+        8-wave variant."""
         self.L.check(self.L.lib.grid_set_coop(self._h, alg, int(mode)), "grid_set_coop")
 
     def get_coop(self, alg, K):
-        return int(self.L.lib.grid_get_coop(self._h, alg, int(K))) == 1
+        """0: no tile-cooperative kernel for a call with K configurations, 1: the 4-wave kernel, 2: the register-lean 8-wave variant."""
+        return max(0, int(self.L.lib.grid_get_coop(self._h, alg, int(K))))
+
+    def lean_available(self, alg):
+        return int(self.L.lib.grid_lean_available(alg)) == 1
 
     def coop_available(self, alg):
         return int(self.L.lib.grid_coop_available(alg)) == 1

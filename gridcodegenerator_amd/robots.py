@@ -3,6 +3,8 @@
 ``iiwa7``   -- 7-DoF KUKA LBR iiwa-14-like serial chain, every joint revolute about z
               (``are_Ss_identical`` and ``is_serial_chain`` are both True: the reference then
               needs no topology table, helpers/_topology_helpers.py:217-226).
+``quad12``  -- 12-DoF HyQ-like quadruped on a fixed trunk: four 3-joint legs, i.e. FOUR base-rooted trees (DFS pre-order
+              ids LF 0-2, RF 3-5, LH 6-8, RH 9-11); sits on the n = 12 switch between the fused and the column-serial schedule.
 ``atlas30`` -- 30-DoF Atlas-v5-like branched humanoid on a fixed pelvis, DFS pre-order ids:
               back 0-2, l_arm 3-9, neck 10, r_arm 11-17, l_leg 18-23, r_leg 24-29.
 
@@ -105,7 +107,30 @@ def chain_prismatic_test_robot():
     return RobotModel("mixed5", joints)
 
 
-BUILTIN_ROBOTS = {"iiwa7": iiwa7, "atlas30": atlas30, "mixed5": chain_prismatic_test_robot}
+def quad12():
+    """HyQ-like quadruped on a fixed trunk: four legs of three revolute joints (hip abduction about x, hip flexion and knee about y),
+    each leg a base-rooted tree of its own -- 12 joints, 4 trees, DFS pre-order ids LF 0-2, RF 3-5, LH 6-8, RH 9-11.  n = 12 is the
+    largest robot on the fused gradient schedule (larger ones use the column-serial recomputing schedule), and four trees exercise the
+    tree-wise machinery (block-diagonal Minv, wave-per-configuration groups) that a chain and a humanoid do not."""
+    joints = []
+    for leg, (sx, sy) in (("lf", (1.0, 1.0)), ("rf", (1.0, -1.0)), ("lh", (-1.0, 1.0)), ("rh", (-1.0, -1.0))):
+        spec = [
+            (leg + "_haa", 0, (sx * 0.3735, sy * 0.207, 0.0), (0.0, 0.0, 0.0), leg + "_hipassembly", 2.93, (sx * 0.04263, sy * 0.0, -0.16931),
+             (0.05071, sx * sy * 4e-05, sx * 0.00159, 0.05486, sy * -5e-05, 0.00571)),
+            (leg + "_hfe", 1, (sx * 0.08, 0.0, 0.0), (0.0, 0.0, 0.0), leg + "_upperleg", 2.638, (sx * 0.01, sy * 0.002, -0.15074),
+             (0.08873, sx * sy * -0.00023, sx * 0.00067, 0.09176, sy * 0.00005, 0.00342)),
+            (leg + "_kfe", 1, (0.0, 0.0, -0.35), (0.0, 0.0, 0.0), leg + "_lowerleg", 0.881, (sx * 0.005, 0.0, -0.1254),
+             (0.02213, 0.0, sx * 0.0001, 0.02218, 0.0, 0.00012)),
+        ]
+        parent = None
+        for (name, axis, xyz, rpy, link, mass, com, inertia) in spec:
+            joints.append(Joint(name, parent, axis=axis, jtype="revolute", xyz=xyz, rpy=rpy, damping=0.0,
+                                link_name=link, mass=mass, com=com, inertia=inertia))
+            parent = name
+    return RobotModel("quad12", joints, base_link_name="trunk")
+
+
+BUILTIN_ROBOTS = {"iiwa7": iiwa7, "atlas30": atlas30, "mixed5": chain_prismatic_test_robot, "quad12": quad12}
 
 
 REGISTERED_ROBOTS = {}

@@ -110,11 +110,19 @@ int grid_get_split(grid_handle *h, int alg, int num_timesteps);
  * shared prefix is computed ONCE per tile.  grid_coop_available: 1 if the generator emitted it for `alg` (GRID_ALG_FD_DU).
  * grid_set_coop: 0 = automatic (default: FD_DU_COOP_AUTO_MIN_TILES of the generated header -- every batch size for large robots in
  * fp32, from 192 tiles on in the mixed arithmetic, never for small robots), 1 = never, 2 = always.
- * grid_get_coop: 1 if a call with `num_timesteps` would dispatch it (it takes precedence over the column split). */
+ * grid_get_coop: which tile-cooperative kernel a call with `num_timesteps` would dispatch -- 0 none, 1 the 4-wave kernel, 2 its
+ * register-lean 8-wave variant (it takes precedence over the column split).
+ * Register-lean variant (`forward_dynamics_gradient_kernel_coop8`, large robots, fp32 arithmetic): EIGHT wavefronts per tile, two per
+ * SIMD at <= 256 registers each -- a block-shared input table, the Minv recursion by base-rooted tree with its carried values parked in
+ * LDS, gradient HALF columns as work items -- so that a second wave fills the issue slots and waits a lone 464-register wave leaves
+ * empty.  grid_lean_available: 1 if emitted; grid_set_coop mode 3 = always this variant; automatic from FD_DU_LEAN_AUTO_MIN_TILES of
+ * the generated header (0: on request only). */
 int grid_coop_available(int alg);
+int grid_lean_available(int alg);
 int grid_set_coop(grid_handle *h, int alg, int mode);
 int grid_get_coop(grid_handle *h, int alg, int num_timesteps);
 int grid_kernel_attributes_coop(int alg, int *out);
+int grid_kernel_attributes_lean(int alg, int *out);
 
 /* ---- wave-per-configuration kernels (all five algorithms): the small-batch path ----
  * The reference's own mapping -- one thread block per configuration whose threads split the 6x6 products and the gradient columns

@@ -75,6 +75,36 @@ __global__ void inner_chain_kernel(T *d_out, const T *d_q_qd_u, const G::robotMo
     G::inverse_dynamics_gradient_inner<T>(s_dc_du, s_q, s_qd, s_vaf, s_XImats, nullptr, gravity);
 }
 
+// The spatial-algebra device library (dot_prod, mxX / mxK families, fx, fx_zeroed, fx_times_v[_peq]: reference
+// helpers/_spatial_algebra_helpers.py:35-257) called from a user kernel, one lane per (x, y) pair.  out row (SPATIAL_ROW values):
+// for K = 0..5: mxX | mxX_scaled | y + mxX_peq | y + mxX_peq_scaled (6 each); fx (36, column-major); fx_zeroed on zeros (36);
+// fx_times_v (6); y + fx_times_v_peq (6); dot_prod<6,1,1>(x, y); dot_prod<3,2,1>(x, y); then mx0..mx5 called by NAME (6 x 6)
+static const int SPATIAL_ROW = 6 * 4 * 6 + 36 + 36 + 6 + 6 + 2 + 36;
+__global__ void spatial_kernel(T *d_out, const T *d_xy, T alpha, int K) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    T x[6], y[6], o[SPATIAL_ROW];
+    for (int i = 0; i < 6; i++) { x[i] = d_xy[(size_t)k * 12 + i]; y[i] = d_xy[(size_t)k * 12 + 6 + i]; }
+    int at = 0;
+    for (int c = 0; c < 6; c++) {
+        G::mxX<T>(o + at, x, c); at += 6;
+        G::mxX_scaled<T>(o + at, x, alpha, c); at += 6;
+        for (int i = 0; i < 6; i++) o[at + i] = y[i];
+        G::mxX_peq<T>(o + at, x, c); at += 6;
+        for (int i = 0; i < 6; i++) o[at + i] = y[i];
+        G::mxX_peq_scaled<T>(o + at, x, alpha, c); at += 6;
+    }
+    G::fx<T>(o + at, x); at += 36;
+    for (int i = 0; i < 36; i++) o[at + i] = static_cast<T>(0);
+    G::fx_zeroed<T>(o + at, x); at += 36;
+    G::fx_times_v<T>(o + at, x, y); at += 6;
+    for (int i = 0; i < 6; i++) o[at + i] = y[i];
+    G::fx_times_v_peq<T>(o + at, x, y); at += 6;
+    o[at] = G::dot_prod<T, 6, 1, 1>(x, y); o[at + 1] = G::dot_prod<T, 3, 2, 1>(x, y); at += 2;
+    G::mx0<T>(o + at, x); G::mx1<T>(o + at + 6, x); G::mx2<T>(o + at + 12, x); G::mx3<T>(o + at + 18, x); G::mx4<T>(o + at + 24, x); G::mx5<T>(o + at + 30, x);
+    for (int i = 0; i < SPATIAL_ROW; i++) d_out[(size_t)k * SPATIAL_ROW + i] = o[i];
+}
+
 struct Ctx {
     hipStream_t *streams; G::robotModel<T> *d_robotModel; G::gridData<T> *hd; int K;
 };
@@ -91,6 +121,23 @@ extern "C" {
 
 const char *as_last_error() { return g_err.c_str(); }
 int as_num_joints() { return N; }
+int as_spatial_row() { return SPATIAL_ROW; }
+
+// The spatial-algebra device library on the GPU: xy [K][12] = (x | y) pairs, out [K][as_spatial_row()].  Returns 0 or 1 (HIP error).
+int as_spatial(const T *xy, T alpha, int K, T *out) {
+    T *d_xy = nullptr, *d_out = nullptr;
+    gpuErrchk(hipMalloc((void **)&d_xy, sizeof(T) * 12 * (size_t)K));
+    gpuErrchk(hipMalloc((void **)&d_out, sizeof(T) * SPATIAL_ROW * (size_t)K));
+    CHK("as_spatial: alloc");
+    gpuErrchk(hipMemcpy(d_xy, xy, sizeof(T) * 12 * (size_t)K, hipMemcpyHostToDevice));
+    spatial_kernel<<<dim3((K + 63) / 64, 1, 1), dim3(64, 1, 1)>>>(d_out, d_xy, alpha, K);
+    gpuErrchk(hipGetLastError());
+    gpuErrchk(hipDeviceSynchronize());
+    gpuErrchk(hipMemcpy(out, d_out, sizeof(T) * SPATIAL_ROW * (size_t)K, hipMemcpyDeviceToHost));
+    (void)hipFree(d_xy); (void)hipFree(d_out);
+    CHK("as_spatial");
+    return 0;
+}
 
 // Run ONE named piece of the surface on K configurations.  q_qd_u [K][3n]; qdd [K][n] and Minv [K][n*n] (upper triangle)
 // where the variant consumes them; `out` receives the variant's result rows (sizes in tests/test_api_surface.py).

@@ -9,7 +9,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 GOLDEN_DIR = os.path.join(REPO, "tests", "golden")
-ROBOTS = ["iiwa7", "atlas30", "mixed5"]
+ROBOTS = ["iiwa7", "atlas30", "mixed5", "quad12"]
 
 
 def pytest_configure(config):

@@ -27,7 +27,7 @@ from reference import GRiDCodeGenerator as RefGen  # noqa: E402
 from gridcodegenerator_amd.robots import get_robot  # noqa: E402
 
 NUM_CONFIGS = 8
-SEEDS = {"iiwa7": 101, "atlas30": 102, "mixed5": 103}
+SEEDS = {"iiwa7": 101, "atlas30": 102, "mixed5": 103, "quad12": 104}
 
 
 def make_inputs(n, seed, K=NUM_CONFIGS):
@@ -47,7 +47,10 @@ def parse_emitted_array(code, name):
 
 
 def main():
+    only = sys.argv[1:]             # (robot names: regenerate only these -- an .npz is a zip archive and carries time stamps)
     for name, seed in SEEDS.items():
+        if only and name not in only:
+            continue
         robot = get_robot(name)
         n = robot.get_num_pos()
         g = RefGen(robot)

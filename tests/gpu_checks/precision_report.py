@@ -10,7 +10,7 @@ from gridcodegenerator_amd.robots import get_robot
 from oracle import rbd_oracle as O
 
 precision = sys.argv[1] if len(sys.argv) > 1 else "fp32"
-robots = sys.argv[2:] or ["iiwa7", "atlas30", "mixed5"]
+robots = sys.argv[2:] or ["iiwa7", "atlas30", "mixed5", "quad12"]
 report = {}
 for robot in robots:
     import os

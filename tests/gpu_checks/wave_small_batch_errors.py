@@ -21,7 +21,7 @@ def main():
     from test_gpu_parity import oracle_all, pack
     Ks = (1, 7, 64, 200)
     print("norm-wise error max|err|/max|ref| of the wave-per-configuration kernels, %s arithmetic; worst over seeds (test seed first)" % host.DEFAULT_PRECISION)
-    for robot in ("iiwa7", "mixed5", "atlas30"):
+    for robot in ("iiwa7", "mixed5", "quad12", "atlas30"):
         T = O.RobotTables(get_robot(robot))
         worst = {}
         with host.GridHandle(robot, device=0, precision=host.DEFAULT_PRECISION) as h:

@@ -123,3 +123,43 @@ def test_api_surface_on_gpu(robot_name, tables):
     assert relerr(got[:, n + n * n:n + n * n + 18 * n], vaf)[0] < tol["c_qdd"]
     assert relerr(got[:, n + n * n + 18 * n:], gflat(O.rnea_grad(T, q64, qd64, qdd_gpu.astype(np.float64))))[0] < tol["dc_du"]
     print("api surface %s: worst norm-wise errors %s" % (robot_name, {k: "%.1e" % v for k, v in sorted(worst.items())}))
+
+
+@pytest.mark.gpu
+def test_spatial_algebra_device_library_on_gpu():
+    """The reference header's device library (helpers/_spatial_algebra_helpers.py:35-257) EXECUTED ON THE GPU from a user kernel
+    (tests/api_surface_harness.hip: spatial_kernel, one lane per (x, y) pair): the runtime-selected mxX family (plain, _scaled, _peq,
+    _peq_scaled), mx0..mx5 by name, fx, fx_zeroed, fx_times_v, fx_times_v_peq and dot_prod against the oracle's cross-product
+    matrices -- mxK(x) = crm(x)[:, K], fx(x) = crf(x) = -crm(x)^T (column-major), fx_times_v(x, y) = crf(x) y."""
+    from oracle import rbd_oracle as O
+    lib = _load("iiwa7")
+    lib.as_spatial.restype = ctypes.c_int
+    lib.as_spatial.argtypes = [FP, ctypes.c_float, ctypes.c_int, FP]
+    lib.as_spatial_row.restype = ctypes.c_int
+    K, row = 130, lib.as_spatial_row()                       # (two full waves + two lanes: the kernel's tail guard is exercised)
+    assert row == 6 * 4 * 6 + 36 + 36 + 6 + 6 + 2 + 36
+    rng = np.random.default_rng(5)
+    xy = rng.uniform(-2, 2, (K, 12)).astype(np.float32)
+    alpha = np.float32(0.37)
+    out = np.full((K, row), np.nan, dtype=np.float32)
+    rc = lib.as_spatial(_p(xy), ctypes.c_float(alpha), K, _p(out))
+    assert rc == 0, lib.as_last_error().decode()
+    assert np.isfinite(out).all()
+    for k in (0, 1, 63, 64, 129):
+        x64, y64 = xy[k, :6].astype(np.float64), xy[k, 6:].astype(np.float64)
+        crm = np.stack([O.mxS(c, x64) for c in range(6)], axis=1)
+        crf = O.fx(x64)
+        o = 0
+        for c in range(6):
+            col = crm[:, c]
+            for expect in (col, col * alpha, y64 + col, y64 + col * alpha):
+                np.testing.assert_allclose(out[k, o:o + 6], expect, rtol=1e-6, atol=1e-6)
+                o += 6
+        for _ in range(2):
+            np.testing.assert_allclose(out[k, o:o + 36].reshape(6, 6).T, crf, rtol=1e-6, atol=1e-6)       # column-major
+            o += 36
+        np.testing.assert_allclose(out[k, o:o + 6], crf @ y64, rtol=1e-5, atol=1e-5); o += 6
+        np.testing.assert_allclose(out[k, o:o + 6], y64 + crf @ y64, rtol=1e-5, atol=1e-5); o += 6
+        np.testing.assert_allclose(out[k, o], x64 @ y64, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(out[k, o + 1], x64[0] * y64[0] + x64[2] * y64[1] + x64[4] * y64[2], rtol=1e-5, atol=1e-6); o += 2
+        np.testing.assert_allclose(out[k, o:o + 36].reshape(6, 6).T, crm, rtol=1e-6, atol=1e-6)           # mx0..mx5 by name = the columns of crm(x)

@@ -156,7 +156,7 @@ def test_generator_emits_coop_kernel(tmp_path, monkeypatch, robots):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("robot", ["iiwa7", "mixed5", "atlas30"])
+@pytest.mark.parametrize("robot", ["iiwa7", "mixed5", "quad12", "atlas30"])
 def test_coop_kernel_on_gpu(robot, tables):
     """Through the C ABI: the tile-cooperative kernel against the oracle and against the single-wave kernel, ragged batches,
     few blocks (grid-stride over tiles), rows past the batch untouched."""

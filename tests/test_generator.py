@@ -75,7 +75,7 @@ def _emitted_declarations(code):
     return out
 
 
-@pytest.mark.parametrize("name", ["iiwa7", "mixed5", "atlas30"])
+@pytest.mark.parametrize("name", ["iiwa7", "mixed5", "quad12", "atlas30"])
 def test_signatures_match_what_the_reference_emits(name, robots, tmp_path):
     """Every kernel, _device function and host wrapper the REFERENCE emits for this robot (recorded by
     tests/golden/make_golden.py from the reference's own output, tests/golden/reference_signatures.json) exists in the

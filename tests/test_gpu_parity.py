@@ -22,24 +22,30 @@ pytestmark = pytest.mark.gpu
 # norm-wise tolerances per arithmetic variant, robot and output: <= 3x measured (see the module docstring)
 _T = lambda c, c_qdd, Minv, qdd, dc_du, df_du, df_du_qdd_minv: dict(c=c, c_qdd=c_qdd, Minv=Minv, qdd=qdd, dc_du=dc_du, df_du=df_du,
                                                                        df_du_qdd_minv=df_du_qdd_minv)
+# quad12 (12-joint quadruped, four 3-joint trees; added in round 4): measured profiles/r04/precision_report_{fp32,mixed}.txt
+QUAD12_FP32 = _T(8e-7, 1e-6, 2e-7, 5e-7, 7e-7, 2e-6, 1.6e-6)
+QUAD12_MIXED = _T(8e-7, 1e-6, 2e-7, 5e-7, 7e-7, 2e-6, 1.6e-6)
 TOL_BY_PRECISION = {
     # measured (profiles/r02/precision_report_fp32.txt, max over the K = 201 and K = 2048 batches):
     #   iiwa7    c 2.8e-7  Minv 6.6e-8  qdd 9.1e-8  dc_du 2.3e-7  df_du 7.2e-7  df_du(qdd, Minv given) 5.5e-7
     #   atlas30  c 2.6e-7  Minv 1.3e-7  qdd 2.7e-7  dc_du 3.5e-7  df_du 5.7e-6  df_du(qdd, Minv given) 5.7e-7
     #   mixed5   c 3.8e-7  Minv 4.2e-8  qdd 1.8e-7  dc_du 1.6e-7  df_du 8.3e-7  df_du(qdd, Minv given) 8.3e-7
     "fp32": {"iiwa7": _T(8e-7, 1e-6, 2e-7, 3e-7, 7e-7, 2e-6, 1.6e-6), "atlas30": _T(8e-7, 1e-6, 4e-7, 8e-7, 1e-6, 1.7e-5, 1.7e-6),
-             "mixed5": _T(1e-6, 1.2e-6, 1.3e-7, 5e-7, 5e-7, 2.5e-6, 2.5e-6)},
+             "mixed5": _T(1e-6, 1.2e-6, 1.3e-7, 5e-7, 5e-7, 2.5e-6, 2.5e-6),
+             "quad12": QUAD12_FP32},
     # measured (precision_report_mixed.txt): iiwa7 Minv 6.2e-8 qdd 6.6e-8 df_du 5.2e-7; mixed5 Minv 3.4e-8 qdd 1.8e-7 df_du 8.3e-7;
     #   atlas30  c 2.6e-7  Minv 5.9e-8  qdd 1.1e-7  dc_du 3.5e-7  df_du 5.5e-7 (K = 333, seed 47: 1.1e-6)  df_du(qdd, Minv given) 5.7e-7
     "mixed": {"iiwa7": _T(8e-7, 1e-6, 2e-7, 2e-7, 7e-7, 1.5e-6, 1.6e-6), "mixed5": _T(1e-6, 1.2e-6, 1e-7, 5e-7, 5e-7, 2.5e-6, 2.5e-6),
-              "atlas30": _T(8e-7, 1e-6, 1.8e-7, 3.3e-7, 1e-6, 2.5e-6, 1.7e-6)},
+              "atlas30": _T(8e-7, 1e-6, 1.8e-7, 3.3e-7, 1e-6, 2.5e-6, 1.7e-6), "quad12": QUAD12_MIXED},
 }
 NORTH_STAR = 1e-6       # "fp32 torques/accelerations within 1e-6 rel"
 # worst ELEMENT-WISE relative error of c and qdd over the entries that are >= 1e-3 of the batch scale (conftest.elementwise_err):
 # <= 3x measured (profiles/r03/precision_report_*.txt, max over the K = 201 and K = 2048 batches:
 #   fp32  iiwa7 c 5.5e-5 qdd 2.2e-5 | atlas30 c 1.2e-4 qdd 4.0e-5 | mixed5 c 1.2e-4 qdd 2.0e-5;   mixed: qdd 1.1e-5 | 2.4e-5 | 1.5e-5)
-ELEMENTWISE = {"fp32": {"iiwa7": dict(c=1.6e-4, qdd=6.6e-5), "atlas30": dict(c=3.6e-4, qdd=1.2e-4), "mixed5": dict(c=3.6e-4, qdd=6e-5)},
-               "mixed": {"iiwa7": dict(c=1.6e-4, qdd=3.3e-5), "atlas30": dict(c=3.6e-4, qdd=7.2e-5), "mixed5": dict(c=3.6e-4, qdd=4.5e-5)}}
+ELEMENTWISE = {"fp32": {"iiwa7": dict(c=1.6e-4, qdd=6.6e-5), "atlas30": dict(c=3.6e-4, qdd=1.2e-4), "mixed5": dict(c=3.6e-4, qdd=6e-5),
+                        "quad12": dict(c=3.6e-4, qdd=1.2e-4)},
+               "mixed": {"iiwa7": dict(c=1.6e-4, qdd=3.3e-5), "atlas30": dict(c=3.6e-4, qdd=7.2e-5), "mixed5": dict(c=3.6e-4, qdd=4.5e-5),
+                         "quad12": dict(c=3.6e-4, qdd=1.2e-4)}}
 
 
 def _default_precision():
@@ -122,7 +128,7 @@ def test_all_algorithms_host_api(robot_name, handles, tables):
     assert relerr(got, ref["df_du"])[0] < tol["df_du_qdd_minv"]
 
 
-@pytest.mark.parametrize("robot", ["iiwa7", "mixed5", "atlas30"])
+@pytest.mark.parametrize("robot", ["iiwa7", "mixed5", "quad12", "atlas30"])
 def test_mixed_precision_meets_the_north_star(robot, handles, tables, torch_cuda):
     """precision="mixed" (the Minv recursion and qdd = Minv (u - c) in double, everything else float): every output within its
     measured tolerance, accelerations within north_star's 1e-6 for every robot, and the forward-dynamics gradient within 1e-6 for
@@ -171,10 +177,20 @@ def test_golden_fixtures(robot_name, handles, golden):
     assert relerr(h.inverse_dynamics(x), Gd["c_noqdd"])[0] < tol["c"]
     assert relerr(h.direct_minv(x), O.flat_colmajor(Gd["Minv_upper"]))[0] < tol["Minv"]
     assert relerr(h.forward_dynamics(x), Gd["qdd"])[0] < tol["qdd"]
-    if robot_name != "mixed5":   # prismatic joints: the reference gradient itself is wrong (tests/test_oracle.py)
-        gflat = lambda M: np.concatenate([O.flat_colmajor(M[:, :, :n]), O.flat_colmajor(M[:, :, n:])], axis=1)
-        assert relerr(h.inverse_dynamics_gradient(x), gflat(Gd["dc_du_noqdd"]))[0] < tol["dc_du"]
-        assert relerr(h.forward_dynamics_gradient(x), gflat(Gd["df_du"]))[0] < tol["df_du"]
+    gflat = lambda M: np.concatenate([O.flat_colmajor(M[:, :, :n]), O.flat_colmajor(M[:, :, n:])], axis=1)
+    if robot_name == "mixed5":
+        # Prismatic joints: the reference seeds a joint's own d/dq column with the MOTION cross product (_test.py:311,437), which finite
+        # differences refute (tests/test_oracle.py); the shipped library uses the force cross product.  The library generated with
+        # prismatic_gradient="reference" (mixed5_refgrad, built by build()) reproduces the reference's choice: ITS gradients are held
+        # to the reference's goldens here, and the shipped library's gradients must differ from them.
+        from gridcodegenerator_amd import host
+        name, base = host.REFERENCE_GRADIENT_VARIANT
+        host.register_variant(name, base, prismatic_gradient="reference")
+        shipped = h.inverse_dynamics_gradient(x)
+        assert relerr(shipped, gflat(Gd["dc_du_noqdd"]))[0] > 1e-3
+        h = handles(name)
+    assert relerr(h.inverse_dynamics_gradient(x), gflat(Gd["dc_du_noqdd"]))[0] < tol["dc_du"]
+    assert relerr(h.forward_dynamics_gradient(x), gflat(Gd["df_du"]))[0] < tol["df_du"]
 
 
 def test_model_tables_uploaded_bit_exact(robot_name, handles, golden):
@@ -234,7 +250,7 @@ def test_column_split_kernels_bitwise(handles, torch_cuda):
         unsplit_regs = h.L.kernel_attributes(alg)["numRegs"]        # <= 256: two waves of the unsplit kernel share a SIMD
         return 2 if (best == 1 and n <= 12 and 2 in splits and unsplit_regs > 256) else best
 
-    for robot in ("iiwa7", "mixed5", "atlas30"):
+    for robot in ("iiwa7", "mixed5", "quad12", "atlas30"):
         h = handles(robot)
         n, K = h.n, 333
         q, qd, u = make_inputs(n, K, 23)

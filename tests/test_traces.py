@@ -252,3 +252,39 @@ def test_optimal_column_sets(setup):
     ref = O.fd_grad(T, q, qd, u)
     want = np.concatenate([ref[:, :, c] for c in cols] + [ref[:, :, spec.n + c] for c in cols], axis=1)
     assert relerr(got, want)[0] < 1e-12
+
+
+def test_reference_prismatic_gradient_option(setup, golden, monkeypatch):
+    """GRiDCodeGenerator(prismatic_gradient="reference"): the d/dq seed of a joint's own column uses the reference's motion cross
+    product (_test.py:311,437).  The traced gradient cores of the prismatic test robot then reproduce what the REFERENCE ITSELF
+    computed (tests/golden/mixed5.npz: dc_du, df_du) -- which the default ("corrected": force cross product, the one finite differences
+    confirm) deliberately does not -- and for a revolute-only robot the two options trace the very same operations."""
+    from gridcodegenerator_amd.emit import algorithms as alg
+    spec, T, q, qd, u = setup("mixed5")
+    n = spec.n
+    Gd = golden("mixed5")
+    qg, qdg, ug = Gd["q"], Gd["qd"], Gd["u"]
+    monkeypatch.setattr(alg, "PRISMATIC_GRADIENT", "reference")
+    got = _run(cores.core_inverse_dynamics_gradient(spec, False), _inputs(n, qg, qdg))
+    assert relerr(got, _grad_flat(Gd["dc_du_noqdd"], n))[0] < 1e-11
+    assert relerr(got, _grad_flat(O.rnea_grad(T, qg, qdg, None, prismatic_fix=False), n))[0] < 1e-12
+    got_fd = _run(cores.core_forward_dynamics_gradient(spec, False), _inputs(n, qg, qdg, u=ug))
+    assert relerr(got_fd, _grad_flat(Gd["df_du"], n))[0] < 1e-9
+    # the column-serial schedule (what the mixed5 library ships) takes the same switch
+    tr_cs = cores.core_gradient_recompute(spec, "id")
+    vals = tr_cs.evaluate(_inputs(n, qg, qdg))
+    got_cs = np.zeros((qg.shape[0], 2 * n * n))
+    for (dst, _), v in zip(tr_cs.outputs, vals):            # (column-serial cores emit the columns in their own order)
+        if not isinstance(dst, str):
+            got_cs[:, int(dst)] = v
+    assert relerr(got_cs, _grad_flat(Gd["dc_du_noqdd"], n))[0] < 1e-11
+    monkeypatch.setattr(alg, "PRISMATIC_GRADIENT", "corrected")
+    corrected = _run(cores.core_inverse_dynamics_gradient(spec, False), _inputs(n, qg, qdg))
+    assert relerr(corrected, _grad_flat(Gd["dc_du_noqdd"], n))[0] > 1e-3            # (the reference's prismatic columns differ)
+    assert relerr(corrected, _grad_flat(O.rnea_grad(T, qg, qdg, None, prismatic_fix=True), n))[0] < 1e-12
+    # revolute-only robot: the same trace either way
+    spec7 = RobotSpec(__import__("gridcodegenerator_amd.robots", fromlist=["get_robot"]).get_robot("iiwa7"))
+    a = cores.core_inverse_dynamics_gradient(spec7, False)
+    monkeypatch.setattr(alg, "PRISMATIC_GRADIENT", "reference")
+    b = cores.core_inverse_dynamics_gradient(spec7, False)
+    assert a.nodes == b.nodes and a.outputs == b.outputs

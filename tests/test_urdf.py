@@ -22,7 +22,7 @@ def _same_robot(a, b, tol=1e-12):
         assert np.abs(a.get_Imat_by_id(j) - b.get_Imat_by_id(j)).max() < tol * max(1.0, np.abs(a.get_Imat_by_id(j)).max())
 
 
-@pytest.mark.parametrize("name", ["iiwa7", "atlas30", "mixed5"])
+@pytest.mark.parametrize("name", ["iiwa7", "atlas30", "mixed5", "quad12"])
 def test_round_trip(name, tmp_path):
     robot = get_robot(name)
     text = urdf.robot_to_urdf(robot)

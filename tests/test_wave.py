@@ -85,7 +85,7 @@ def interpret_wave_cores(spec, q, qd, u, gravity=9.81, dtype="float64", use_role
     return out
 
 
-@pytest.mark.parametrize("name", ["iiwa7", "mixed5", "atlas30"])
+@pytest.mark.parametrize("name", ["iiwa7", "mixed5", "quad12", "atlas30"])
 def test_wave_cores_match_the_oracle_on_the_cpu(name, robots, tables):
     from oracle import rbd_oracle as O
     spec = RobotSpec(robots(name))
@@ -100,7 +100,7 @@ def test_wave_cores_match_the_oracle_on_the_cpu(name, robots, tables):
     assert np.abs(plain - ref).max() < 1e-10 * max(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("name", ["iiwa7", "mixed5", "atlas30"])
+@pytest.mark.parametrize("name", ["iiwa7", "mixed5", "quad12", "atlas30"])
 def test_wave_cores_of_the_other_algorithms_on_the_cpu(name, robots, tables):
     """The same phases serve RNEA, Minv, forward dynamics and the RNEA gradient (the small-batch path of every kernel)."""
     from oracle import rbd_oracle as O
@@ -126,7 +126,7 @@ def test_wave_groups_are_runs_of_base_trees(robots):
     assert wave.wave_groups(RobotSpec(robots("iiwa7"))) == [(0, 7)]
     assert wave.wave_roles(spec, wave.wave_groups(spec)) == {1: 0}        # the legs' wave runs the torso group's first RNEA pass
     assert wave.wave_roles(RobotSpec(robots("iiwa7")), [(0, 7)]) == {}
-    for name in ("iiwa7", "mixed5", "atlas30"):
+    for name in ("iiwa7", "mixed5", "quad12", "atlas30"):
         s = RobotSpec(robots(name))
         groups = wave.wave_groups(s)
         assert sorted(j for (f, m) in groups for j in range(f, f + m)) == list(range(s.n))
@@ -150,7 +150,7 @@ def test_generated_header_has_the_wave_kernel(tmp_path, monkeypatch, robots):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("robot", ["iiwa7", "mixed5", "atlas30"])
+@pytest.mark.parametrize("robot", ["iiwa7", "mixed5", "quad12", "atlas30"])
 def test_wave_kernel_on_gpu(robot, tables):
     """Through the C ABI at K = 1, 7, 64, 200 (+ a strided launch with few blocks): against the oracle, against the
     lane-per-configuration kernel, rows past the batch untouched; the automatic choice follows the generated header."""
@@ -193,7 +193,7 @@ def test_wave_kernel_on_gpu(robot, tables):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("robot", ["iiwa7", "mixed5", "atlas30"])
+@pytest.mark.parametrize("robot", ["iiwa7", "mixed5", "quad12", "atlas30"])
 def test_wave_kernels_of_the_other_algorithms_on_gpu(robot, tables):
     """RNEA (with and without qdd), Minv, forward dynamics and the RNEA gradient (with and without qdd) through the C ABI with the
     wave-per-configuration kernels forced, K = 1, 7, 64, 200: against the oracle and against the lane-per-configuration kernels."""
