@@ -17,8 +17,9 @@ Sharding: the batch dimension is embarrassingly parallel, every rank owns its ow
 barrier and the max-over-ranks of the elapsed time.
 
 roofline: algorithmic bytes per launch = 4*(3n + 2n^2) * batch, divided by the
-kernel's average launch duration.  Three clocks see a launch in this run -- HIP events recorded on the launch stream around the timed
-region itself, HIP events around a further set of back-to-back launches (grid_time_device), and the host's wall clock per step --
+kernel's average launch duration.  Three clocks see a launch in this run -- the host's wall clock per step of the timed region, HIP
+events recorded on the launch stream around a repetition of exactly that region (same K steps; the events' host cost stays out of the
+timed region), and HIP events around a further set of back-to-back launches (grid_time_device) --
 and ``roofline.achieved`` / ``frac`` are priced on the SLOWEST of them; ``roofline.clock`` names it, ``clocks_us`` lists all three.
 ``secondary`` holds the other single-GPU configurations of BASELINE.json (C2, C3's forward dynamics, C4) and north_star's Atlas-30
 batch-16k target, each with its own ``roofline``.  ``kernel`` is the
@@ -248,12 +249,16 @@ class Workload:
         host, torch = self.host, self.torch
         # HIP events on the launch stream around the timed region itself (torch events are recorded on torch's current stream, which
         # IS the launch stream here: main() makes a stream of its own current and Workload.stream is that stream)
+        # the timed region proper: barrier + synchronize, exactly K steps, synchronize + barrier -- nothing else inside (two event
+        # records cost the host ~10 us, 5 % of a 20-step region)
+        elapsed = sharding.timed_steps(self.step, steps, warmup, torch.cuda.synchronize, dist, reduce_device=reduce_device)
+        # ... and the same K steps once more with HIP events recorded on the launch stream around them: the kernel time of the region
         ev = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)] if self.n_streams == 1 else None
-        if ev:      # (a torch event is created lazily by its first record(): ~30 us of host time that would sit INSIDE a 200 us timed region)
-            ev[0].record(); ev[1].record(); torch.cuda.synchronize()
-        elapsed = sharding.timed_steps(self.step, steps, warmup, torch.cuda.synchronize, dist, reduce_device=reduce_device,
-                                       on_start=(lambda: ev[0].record()) if ev else None, on_stop=(lambda: ev[1].record()) if ev else None)
-        region_ms = (ev[0].elapsed_time(ev[1]) / steps) if ev else None
+        region_ms = None
+        if ev:
+            ev[0].record(); ev[1].record(); torch.cuda.synchronize()       # (a torch event is created by its first record())
+            sharding.timed_steps(self.step, steps, 0, torch.cuda.synchronize, None, on_start=lambda: ev[0].record(), on_stop=lambda: ev[1].record())
+            region_ms = ev[0].elapsed_time(ev[1]) / steps
         reps = max(20, min(steps, 200)) if self.K <= 65536 else max(5, min(steps, 20))
         b2b_ms = self.h.time_device(self.alg, self.d_out.data_ptr(), self.d_in.data_ptr(), 3 * self.n, self.K, gravity=GRAVITY,
                                     blocks=self.blocks, threads=self.threads, stream=self.stream, reps=reps)

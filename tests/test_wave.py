@@ -149,6 +149,55 @@ def test_generated_header_has_the_wave_kernel(tmp_path, monkeypatch, robots):
     assert any("forward_dynamics_gradient_kernel_wave" in k for k in gen.kernel_instances)
 
 
+# Norm-wise errors of the wave-per-configuration kernels MEASURED on MI355X at the batch sizes used below (worst of six seeds per cell,
+# the tests' own seeds among them; tests/gpu_checks/wave_small_batch_errors.py -> profiles/r04/wave_small_batch_errors.txt, fp32
+# arithmetic).  Every bound below is 3x its cell -- the rule of the whole suite -- instead of a blanket factor for small batches: over one
+# or a few configurations max|err| / max|ref| is noisier, but only the forward-dynamics gradient shows it (Atlas-30: 9.9e-6 at K = 1
+# against 3.7e-6 at K = 200).
+WAVE_MEASURED = {
+    "iiwa7": {
+        "c": {1: 1.4e-07, 7: 2.1e-07, 64: 2.4e-07, 200: 2.6e-07},
+        "c_qdd": {1: 1.9e-07, 7: 2.5e-07, 64: 3.4e-07, 200: 2.6e-07},
+        "Minv": {1: 5.4e-08, 7: 5.5e-08, 64: 6.2e-08, 200: 6.7e-08},
+        "qdd": {1: 8.9e-08, 7: 1.4e-07, 64: 8.4e-08, 200: 1.2e-07},
+        "dc_du_noqdd": {1: 2.4e-07, 7: 1.9e-07, 64: 2.6e-07, 200: 2.3e-07},
+        "dc_du": {1: 2e-07, 7: 2.1e-07, 64: 2.6e-07, 200: 2.5e-07},
+        "df_du": {1: 6.1e-07, 7: 1.3e-06, 64: 8.3e-07, 200: 5.7e-07},
+    },
+    "mixed5": {
+        "c": {1: 3.2e-07, 7: 4.6e-07, 64: 4.2e-07, 200: 3.8e-07},
+        "c_qdd": {1: 3.9e-07, 7: 1.8e-07, 64: 2.8e-07, 200: 2.8e-07},
+        "Minv": {1: 2.2e-08, 7: 3.7e-08, 64: 4e-08, 200: 4.2e-08},
+        "qdd": {1: 8e-08, 7: 7.6e-08, 64: 1.7e-07, 200: 1.7e-07},
+        "dc_du_noqdd": {1: 2.6e-07, 7: 2.3e-07, 64: 1.7e-07, 200: 2e-07},
+        "dc_du": {1: 1.8e-07, 7: 1.9e-07, 64: 1.5e-07, 200: 2.2e-07},
+        "df_du": {1: 5.1e-06, 7: 3.2e-06, 64: 3.3e-06, 200: 1.4e-06},
+    },
+    "quad12": {
+        "c": {1: 1.2e-07, 7: 1.4e-07, 64: 1.5e-07, 200: 2.3e-07},
+        "c_qdd": {1: 2e-07, 7: 1.5e-07, 64: 1.7e-07, 200: 1.9e-07},
+        "Minv": {1: 7.6e-08, 7: 1.1e-07, 64: 1.5e-07, 200: 1.4e-07},
+        "qdd": {1: 2e-07, 7: 1.7e-07, 64: 1.7e-07, 200: 2.5e-07},
+        "dc_du_noqdd": {1: 1.5e-07, 7: 1.6e-07, 64: 1.6e-07, 200: 1.9e-07},
+        "dc_du": {1: 1.5e-07, 7: 1.6e-07, 64: 1.7e-07, 200: 1.9e-07},
+        "df_du": {1: 3e-07, 7: 2.7e-07, 64: 2.7e-07, 200: 2.8e-07},
+    },
+    "atlas30": {
+        "c": {1: 9.1e-08, 7: 1.6e-07, 64: 2.6e-07, 200: 2.2e-07},
+        "c_qdd": {1: 1.2e-07, 7: 2.1e-07, 64: 2.4e-07, 200: 2.8e-07},
+        "Minv": {1: 1.1e-07, 7: 1.1e-07, 64: 1.6e-07, 200: 1.4e-07},
+        "qdd": {1: 3.2e-07, 7: 1.7e-07, 64: 2.2e-07, 200: 2.8e-07},
+        "dc_du_noqdd": {1: 1.9e-07, 7: 3.8e-07, 64: 3e-07, 200: 2.9e-07},
+        "dc_du": {1: 5.6e-07, 7: 2.7e-07, 64: 2.5e-07, 200: 3.2e-07},
+        "df_du": {1: 9.9e-06, 7: 9.7e-06, 64: 4.6e-06, 200: 3.7e-06},
+    },
+}
+
+
+def wave_tol(robot, key, K):
+    return 3.0 * WAVE_MEASURED[robot][key][K]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("robot", ["iiwa7", "mixed5", "quad12", "atlas30"])
 def test_wave_kernel_on_gpu(robot, tables):
@@ -184,8 +233,8 @@ def test_wave_kernel_on_gpu(robot, tables):
                 outs.append(o[:K])
             assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
             err = relerr(outs[0], ref["df_du"])[0]
-            assert err < TOL[robot]["df_du"] * (4 if K < 64 else 1), (robot, K, err)
-            assert relerr(outs[0], plain.cpu().numpy().astype(np.float64))[0] < 2 * TOL[robot]["df_du"]
+            assert err < wave_tol(robot, "df_du", K), (robot, K, err)
+            assert relerr(outs[0], plain.cpu().numpy().astype(np.float64))[0] < 2 * max(TOL[robot]["df_du"], wave_tol(robot, "df_du", K))
             # structural zeros (columns and rows of different base-rooted trees) are written as exact zeros
             zero = np.abs(ref["df_du"]).max(axis=0) == 0.0
             assert np.all(outs[0][:, zero] == 0.0)
@@ -248,7 +297,7 @@ def test_wave_kernels_of_the_other_algorithms_on_gpu(robot, tables):
             tol = TOL[robot]
             for key in got:
                 assert np.array_equal(got[key], few[key]), key
-                t = tol[{"dc_du_noqdd": "dc_du"}.get(key, key)] * (4 if K < 64 else 1)
+                t = wave_tol(robot, key, K)
                 assert relerr(got[key], ref[key])[0] < t, (robot, K, key, relerr(got[key], ref[key])[0])
                 assert relerr(got[key], plain[key].astype(np.float64))[0] < 2 * t, (robot, K, key)
             # entries that couple different base-rooted trees are written as exact zeros
