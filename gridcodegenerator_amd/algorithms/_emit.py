@@ -1486,6 +1486,20 @@ class AlgorithmEmitMixin:
     # ------------------------------------------------------------------------------------------
     # wave-per-configuration forward-dynamics gradient: the lanes of ONE wavefront share a configuration
     # ------------------------------------------------------------------------------------------
+    def _wave_spread_lines(self, kernel):
+        """Launcher lines of a wave-per-configuration kernel compiled for two waves per SIMD: the dynamic LDS request is padded so that a
+        CU's 160 KB admit only as many blocks as an EVEN spread over the 256 CUs needs (ceil(blocks / 256)).  Without it the dispatcher
+        packs twice the blocks on some CUs and leaves others idle as soon as the registers allow it: Atlas-30 dFD at K = 512 25.6 us
+        against 20.9 us for the 295-register build, which the register file itself limits to two blocks per CU
+        (profiles/r04/wave_occupancy.txt)."""
+        if self.wave_occupancy <= 1:
+            return []
+        return ["{   // spread: at most ceil(blocks / CUs) blocks fit one CU's LDS",
+                "    const int per_cu = (blocks + GRID_NUM_CUS - 1)/GRID_NUM_CUS;",
+                "    const size_t spread = (size_t)GRID_LDS_PER_CU/(size_t)(per_cu < 1 ? 1 : per_cu);",
+                "    if (spread > lds_bytes){lds_bytes = spread;}",
+                "}"]
+
     def _wave_occupancy_arg(self):
         """Second __launch_bounds__ argument of the wave-per-configuration kernels (waves per SIMD the compiler must leave room for).
         Large robots: 2 -- a block is one configuration, at 295 registers 512 blocks were resident and the time per launch doubled
@@ -1537,6 +1551,8 @@ class AlgorithmEmitMixin:
                                % (self.wave_auto_max_k if n > 12 else 0))
         self.gen_add_code_line("const int FD_DU_WAVE_SHARED_MEM_COUNT = %d; // dynamic LDS of a block in T elements (%d per wave: uniform table, published Minv, output image)"
                                % (per_wave * W, per_wave))
+        if self.wave_occupancy > 1:
+            self.gen_add_code_line("const int GRID_NUM_CUS = 256; const int GRID_LDS_PER_CU = 160*1024; // MI355X: what the wave launchers spread their blocks over")
         roles = wave.wave_roles(self.spec, groups)                 # {helper wave: helped wave}
         helped_by = {hd: hr for hr, hd in roles.items()}
         self.wave_stats["roles"] = dict(roles)
@@ -1637,6 +1653,15 @@ class AlgorithmEmitMixin:
         self.gen_add_code_line("bool forward_dynamics_gradient_wave_launch(T *d_df_du, const T *d_q_qd_u, const int stride_q_qd_u, const robotModel<T> *d_robotModel, "
                                "const T gravity, const int num_timesteps, int blocks, hipStream_t stream) {", True)
         self.gen_add_code_lines([
+        ] + ([
+            "size_t lds_bytes = (size_t)FD_DU_WAVE_SHARED_MEM_COUNT*sizeof(T);",
+            "static thread_local int configured_device = -1;        // the padded request (spread) exceeds 64 KiB: enabled once per device",
+            "int dev = 0; gpuErrchk(hipGetDevice(&dev));",
+            "if (configured_device != dev){",
+            "    gpuErrchk(hipFuncSetAttribute(reinterpret_cast<const void *>(&forward_dynamics_gradient_kernel_wave<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_bytes > GRID_LDS_PER_CU ? lds_bytes : (size_t)GRID_LDS_PER_CU)));",
+            "    configured_device = dev;",
+            "}",
+        ] if self.wave_occupancy > 1 else [
             "const size_t lds_bytes = (size_t)FD_DU_WAVE_SHARED_MEM_COUNT*sizeof(T);",
             "static thread_local int configured_device = -1;        // > 64 KiB of dynamic LDS must be enabled once per device",
             "int dev = 0; gpuErrchk(hipGetDevice(&dev));",
@@ -1644,8 +1669,10 @@ class AlgorithmEmitMixin:
             "    gpuErrchk(hipFuncSetAttribute(reinterpret_cast<const void *>(&forward_dynamics_gradient_kernel_wave<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));",
             "    configured_device = dev;",
             "}",
+        ]) + [
             "if (blocks <= 0 || blocks > num_timesteps){blocks = num_timesteps;}",
             "if (blocks > 8*SUGGESTED_MAX_BLOCKS){blocks = 8*SUGGESTED_MAX_BLOCKS;}",
+        ] + self._wave_spread_lines("forward_dynamics_gradient_kernel_wave") + [
             "forward_dynamics_gradient_kernel_wave<T><<<dim3(blocks,1,1),dim3(%d,1,1),lds_bytes,stream>>>(d_df_du,d_q_qd_u,stride_q_qd_u,d_robotModel,gravity,num_timesteps);" % (W * WAVE),
             "gpuErrchk(hipGetLastError());",
             "return true;",
@@ -1764,10 +1791,18 @@ class AlgorithmEmitMixin:
             self.gen_add_code_line(launch_sig + " {", True)
             args = ["d_" + out_name, "d_" + in_name, "stride_" + in_name] + (["d_qdd"] if has_qdd else []) + ["d_robotModel"] + (["gravity"] if grav else []) + ["num_timesteps"]
             self.gen_add_code_lines([
+            ] + ([
+                "size_t lds_bytes = (size_t)FD_DU_WAVE_SHARED_MEM_COUNT*sizeof(T);",
+                "static thread_local int configured_device = -1;",
+                "int dev = 0; gpuErrchk(hipGetDevice(&dev));",
+                "if (configured_device != dev){gpuErrchk(hipFuncSetAttribute(reinterpret_cast<const void *>(&%s_kernel_wave<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_bytes > GRID_LDS_PER_CU ? lds_bytes : (size_t)GRID_LDS_PER_CU))); configured_device = dev;}" % base,
+            ] if self.wave_occupancy > 1 else [
                 "const size_t lds_bytes = (size_t)FD_DU_WAVE_SHARED_MEM_COUNT*sizeof(T);",
                 "if (lds_bytes > 65536){gpuErrchk(hipFuncSetAttribute(reinterpret_cast<const void *>(&%s_kernel_wave<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));}" % base,
+            ]) + [
                 "if (blocks <= 0 || blocks > num_timesteps){blocks = num_timesteps;}",
                 "if (blocks > 8*SUGGESTED_MAX_BLOCKS){blocks = 8*SUGGESTED_MAX_BLOCKS;}",
+            ] + self._wave_spread_lines("%s_kernel_wave" % base) + [
                 "%s_kernel_wave<T><<<dim3(blocks,1,1),dim3(%d,1,1),lds_bytes,stream>>>(%s);" % (base, W * WAVE, ",".join(args)),
                 "gpuErrchk(hipGetLastError());",
                 "return true;",

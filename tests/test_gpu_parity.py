@@ -495,13 +495,16 @@ def test_minv_times_mass_matrix_on_gpu(handles, torch_cuda):
     assert np.abs(np.einsum("kij,kjl->kil", Mi, M) - np.eye(n)).max() < 5e-4
 
 
-def test_single_timing_twins(torch_cuda):
-    """The *_single_timing host wrappers / *_kernel_single_timing kernels of the generated header (reference mode 1):
-    a GRiD-style main() compiled with hipcc against the iiwa-7 header must leave the same results in the host buffers
-    as the mode-0 wrappers and print the reference's `Single Call <label>` lines."""
+@pytest.mark.parametrize("robot", ["iiwa7", "atlas30"])
+def test_single_timing_twins(robot, torch_cuda):
+    """The *_single_timing host wrappers / *_kernel_single_timing kernels of the generated header (reference mode 1:
+    algorithms/_inverse_dynamics.py:407-420,482-494): a GRiD-style main() compiled with hipcc against the robot's header must leave the
+    same results in the host buffers as the mode-0 wrappers and print the reference's `Single Call <label>` lines.  iiwa-7: bitwise.
+    Atlas-30: its mode-0 forward-dynamics gradient is served by the tile-cooperative kernel, so that pair is compared norm-wise (2e-5);
+    the harness links the robot's kernel library and compiles only the latency twins."""
     import subprocess
     from gridcodegenerator_amd import host
-    exe = host.build_single_timing_harness("iiwa7", host.DEFAULT_PRECISION)      # prebuilt by build(); rebuilt only if stale
+    exe = host.build_single_timing_harness(robot, host.DEFAULT_PRECISION)      # prebuilt by build(); rebuilt only if stale
     run = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     out = run.stdout
     assert run.returncode == 0 and "ALL MATCH" in out, out
