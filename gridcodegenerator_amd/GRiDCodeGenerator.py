@@ -152,7 +152,7 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, SpatialAlgebraEmitMixin, Al
         self.coop_hoist = bool(exp["coop_hoist"])
         self.lean_probe = exp["lean_probe"]
         self.wave_occupancy = int(exp["wave_occupancy"])
-        self.split_flush_slots = float(exp["split_flush_slots"])
+        self.split_flush_slots = exp["split_flush_slots"] if exp["split_flush_slots"] == "flush" else float(exp["split_flush_slots"])
         self.split_asym = float(exp["split_asym"])
         self.lean_plan_options = dict(exp["lean_plan"])
         self.lean_read_ahead = int(exp["lean_read_ahead"])

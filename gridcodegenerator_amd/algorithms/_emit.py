@@ -491,7 +491,7 @@ class AlgorithmEmitMixin:
                 parts, est = cores.optimal_column_sets(self.spec, S, full)
                 if self.split_half_columns:
                     hparts, hest = cores.optimal_half_column_sets(self.spec, S, full, per_value=self.split_flush_slots)
-                    est_cmp = est + self.split_flush_slots * n * max(2 * len(c_) for c_ in parts)       # (same measure for whole columns)
+                    est_cmp = est + (10.0 if self.split_flush_slots == "flush" else self.split_flush_slots) * n * max(2 * len(c_) for c_ in parts)       # (same measure for whole columns)
                     if hest < 0.98 * est_cmp and all(64 * n * max(len(lo), len(hi)) <= self.lds_per_wave("FD_DU") for (lo, hi) in hparts):
                         parts, est = hparts, hest
             else:

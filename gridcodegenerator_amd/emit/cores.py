@@ -718,6 +718,10 @@ def optimal_column_sets(spec, S, full):
     return parts, best[0]
 
 
+WAVE_LANES = 64
+FLUSH_FIXED_SLOTS = 40.0        # wave syncs, address set-up and the LDS round trips of one flush, in issue slots
+
+
 def optimal_half_column_sets(spec, S, full, restarts=20, weights=None, per_value=0.0):
     """Partition of the 2n HALF columns -- (column, d/dq) and (column, d/dqd) are separate items: the two halves of a gradient column
     share nothing but the prefix -- into S groups minimising the largest group's arithmetic (cost of a group = live arithmetic nodes
@@ -760,7 +764,21 @@ def optimal_half_column_sets(spec, S, full, restarts=20, weights=None, per_value
             m = 0
             for it in key:
                 m |= bits[it]
-            memo[key] = bin(m).count("1") + per_value * n * len(key)
+            if per_value == "flush":
+                # what the two flushes of a group (grid_out_colset2: its d/dq values, then its d/dqd values) execute: LEN staging writes,
+                # then GRID_WAVE_SIZE / G iterations of (LDS read + store) with G = 64 / pow2ceil(LEN) configurations per iteration --
+                # 14 values: 16 iterations, 21 or 28: 32, 35: 64 (29 of 64 lanes idle) -- plus the wave syncs and address set-up
+                extra = 0.0
+                for half in (0, 1):
+                    length = n * sum(1 for (_, h) in key if h == half)
+                    if length:
+                        p2 = 1
+                        while p2 < length:
+                            p2 *= 2
+                        extra += length + 2.0 * (WAVE_LANES // max(1, WAVE_LANES // p2)) + FLUSH_FIXED_SLOTS
+                memo[key] = bin(m).count("1") + extra
+            else:
+                memo[key] = bin(m).count("1") + per_value * n * len(key)
         return memo[key]
     wts = [1.0] * S if weights is None else list(weights)
     gcost = lambda k, group: (cost0(group) * wts[k]) if group else 0.0

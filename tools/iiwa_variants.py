@@ -8,6 +8,9 @@ sys.path.insert(0, REPO)
 VARIANTS = {
     "iiwa7_fl10": dict(experimental={"split_flush_slots": 10}),
     "iiwa7_fl20": dict(experimental={"split_flush_slots": 20}),
+    "iiwa7_fl6": dict(experimental={"split_flush_slots": 6}),
+    "iiwa7_fl14": dict(experimental={"split_flush_slots": 14}),
+    "iiwa7_flx": dict(experimental={"split_flush_slots": "flush"}),      # the flush's own instruction count (iterations by run length) instead of a per-value rate
     "iiwa7_asym100": dict(experimental={"split_flush_slots": 10, "split_asym": 1.0}),
     "iiwa7_asym140": dict(experimental={"split_flush_slots": 10, "split_asym": 1.4}),
     "iiwa7_asym176": dict(experimental={"split_flush_slots": 10, "split_asym": 1.76}),
