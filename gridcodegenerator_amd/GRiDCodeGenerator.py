@@ -321,6 +321,7 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, SpatialAlgebraEmitMixin, Al
         self.gen_init_gridData()
         self.gen_load_update_XImats_helpers(use_thread_group)
         self.gen_spatial_algebra_helpers()       # (after the first algorithm-section function: per-function object-cache keys, host.py)
+        self.gen_launch_shape_fold()
         self.gen_inverse_dynamics(use_thread_group)
         self.gen_direct_minv(use_thread_group)
         self.gen_forward_dynamics(use_thread_group)

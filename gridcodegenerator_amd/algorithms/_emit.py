@@ -642,7 +642,7 @@ class AlgorithmEmitMixin:
             self.gen_add_code_line("        const dim3 block_dimms, const dim3 thread_dimms%s) {" % tail, True)
             single = (mode == "single_timing")
             one = (lambda line: line.replace("*num_timesteps*sizeof(T)", "*sizeof(T)")) if single else (lambda line: line)
-            self.gen_add_code_line("dim3 blocks, threads; grid_launch_dims(block_dimms, thread_dimms, %s, &blocks, &threads);"
+            self.gen_add_code_line("dim3 blocks, threads; grid_launch_dims(block_dimms, thread_dimms, %s, &blocks, &threads); grid_fold_launch_z(&blocks, &threads);"
                                    % ("1" if single else "num_timesteps"))
             self.gen_add_code_line("const size_t lds_bytes = grid_lds_bytes<T>(threads, %d);" % self.lds_per_wave(alg))
             stream = {"full": "streams[0]", "single_timing": "streams[0]", "compute_only": "0", "launch": "stream"}[mode]
@@ -693,6 +693,19 @@ class AlgorithmEmitMixin:
             "}",
             "",
         ])
+
+    def gen_launch_shape_fold(self):
+        """`grid_fold_launch_z`: the kernels number their threads and blocks by the x and y extents only (the reference's kernels do:
+        helpers/_code_generation_helpers.py:41-55); a z extent would give several hardware waves the same thread id -- the same
+        staging region, overwritten while another wave flushes it.  The dim3 host wrappers therefore fold z into y (same number of
+        threads / blocks, unique flat ids).  Emitted inside the algorithm section: no kernel's object-cache key depends on it."""
+        self.gen_add_func_doc("Fold the z extents of a launch shape into y", ["the kernels index threads as x + y*size_x and blocks as x + y*count_x; a z extent",
+                                                                            "would repeat ids (two waves sharing one LDS staging region)"], [], None)
+        self.gen_add_code_lines(["__host__ inline",
+                                 "void grid_fold_launch_z(dim3 *blocks, dim3 *threads){",
+                                 "    if (threads->z > 1){threads->y *= threads->z; threads->z = 1;}",
+                                 "    if (blocks->z > 1){blocks->y *= blocks->z; blocks->z = 1;}",
+                                 "}", ""])
 
     # ------------------------------------------------------------------------------------------
     # load_update_XImats_helpers (lane-private sin/cos table)
@@ -1168,7 +1181,7 @@ class AlgorithmEmitMixin:
         self.gen_add_code_line("void forward_dynamics_gradient_rollout_launch(T *d_traj, const T *d_x0, const T *d_u_traj, const T dt, const robotModel<T> *d_robotModel,")
         self.gen_add_code_line("        const T gravity, const int num_timesteps, const int num_steps, const dim3 block_dimms, const dim3 thread_dimms, hipStream_t stream) {", True)
         self.gen_add_code_lines([
-            "dim3 blocks, threads; grid_launch_dims(block_dimms, thread_dimms, num_timesteps, &blocks, &threads);",
+            "dim3 blocks, threads; grid_launch_dims(block_dimms, thread_dimms, num_timesteps, &blocks, &threads); grid_fold_launch_z(&blocks, &threads);",
             "const size_t lds_bytes = grid_lds_bytes<T>(threads, %d);" % self.lds_per_wave("ROLLOUT"),
             "forward_dynamics_gradient_rollout_kernel<T><<<blocks,threads,lds_bytes,stream>>>(d_traj,d_x0,d_u_traj,dt,d_robotModel,gravity,num_timesteps,num_steps);",
             "gpuErrchk(hipGetLastError());",

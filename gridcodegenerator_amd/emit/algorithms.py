@@ -278,10 +278,10 @@ def minv_backward_lean(tr, spec, I, X_back, publish, joints, cols=None):
             IAj = IA_of(j)
             Uj = [IAj[r][s] for r in range(6)]
             Dj = tr.rcp(Uj[s])
-            if p != -1:                      # (the forward pass of a base joint needs neither)
+            if p != -1:                      # (a base joint's U is never needed)
                 for r in range(6):
                     publish("U", j, r, Uj[r])
-                publish("D", j, 0, Dj)
+            publish("D", j, 0, Dj)
             Mj = {j: Dj}
             mine = [k for k in spec.subtree[j] if wanted(k)]
             for k in mine:
@@ -360,6 +360,74 @@ def minv_forward_lean(tr, spec, X_fwd, fetch, cols, on_final):
                 if all(x.is_zero() for x in Fjk):
                     continue
                 Fn[(j, k)] = Fjk
+
+
+def minv_columns_lean(tr, spec, X_of, fetch, cols, on_final):
+    """Columns `cols` of Minv from the PUBLISHED articulated-inertia chain alone (minv_backward_lean with cols = [] publishes U_j and
+    1/D_j of every joint and nothing else): everything else in the Minv recursion is independent per column, so the waves of a block
+    divide it by columns with no further exchange.  For each column k: the backward pass's F recursion from joint k up to the base
+    (Minv[j][k] = -F[j][s_j] / D_j for the ancestors j of k; _direct_minv first loop, restricted to the column), then the forward
+    pass down every joint j <= k of the tree (second loop).  The backward-pass entries never leave the wave's registers.
+    fetch("U" | "D", j, i): the published values; X_of(j): X_j(q_j) built from re-read sin / cos (once per pass);
+    on_final(j, k, value): Minv[j][k] (j <= k) has its final value."""
+    n = spec.n
+    cols = sorted(cols)
+    tree_root = {}
+    for j in range(n):
+        tree_root[j] = j if spec.parent[j] == -1 else tree_root[spec.parent[j]]
+    roots = sorted(set(tree_root[k] for k in cols))
+    with tr.mixed_region():
+        for root in roots:
+            mine_all = [k for k in cols if tree_root[k] == root]
+            joints = [j for j in range(n) if tree_root[j] == root and j <= mine_all[-1]]
+            # ---- backward: F[(j, k)] for the joints j on the path base -> k, from k upwards
+            F, M = {}, {}
+            for j in reversed(joints):
+                mine = [k for k in mine_all if k in spec.subtree[j]]
+                if not mine:
+                    continue
+                p, s = spec.parent[j], spec.S_ind[j]
+                Dj = fetch("D", j, 0)
+                for k in mine:
+                    M[(j, k)] = Dj if k == j else -(Dj * F[(j, k)][s])
+                if p == -1:
+                    continue
+                Uj = [fetch("U", j, r) for r in range(6)]
+                Xj = X_of(j)
+                for k in mine:
+                    Fjk = F.pop((j, k), None)
+                    upd = [Uj[r] * M[(j, k)] for r in range(6)]
+                    Fjk = upd if Fjk is None else vadd(Fjk, upd)
+                    F[(p, k)] = mattvec(tr, Xj, Fjk)
+            # ---- forward: every joint j <= k of the tree, in id order
+            Fn = {}
+            for j in joints:
+                mine = [k for k in mine_all if k >= j]
+                if not mine:
+                    continue
+                p, s = spec.parent[j], spec.S_ind[j]
+                need_X = (p != -1) or bool(spec.children[j])
+                Xj = X_of(j) if need_X else None
+                if p != -1:
+                    UX = mattvec(tr, Xj, [fetch("U", j, r) for r in range(6)])
+                    Dj = fetch("D", j, 0)
+                Mj = {}
+                for k in mine:
+                    val = M.get((j, k), tr.zero())
+                    if p != -1 and (p, k) in Fn:
+                        val = val - Dj * tr.dot([(UX[r], Fn[(p, k)][r]) for r in range(6)])
+                    Mj[k] = val
+                    on_final(j, k, val)
+                if not spec.children[j]:
+                    continue
+                for k in mine:
+                    Fjk = zeros6(tr)
+                    Fjk[s] = Mj[k]
+                    if p != -1 and (p, k) in Fn:
+                        Fjk = matvec_acc(tr, Xj, Fn[(p, k)], Fjk)
+                    if all(x.is_zero() for x in Fjk):
+                        continue
+                    Fn[(j, k)] = Fjk
 
 
 def minv_sym(Minv, r, c):

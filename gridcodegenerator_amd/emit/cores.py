@@ -273,7 +273,8 @@ def lean_barriers(tr):
     return [pos for (dst, _), pos in zip(tr.outputs, tr.out_pos) if dst == "barrier"]
 
 
-def lean_plan(spec, waves=LEAN_WAVES, max_parked=3, younger_speed=None):
+def lean_plan(spec, waves=LEAN_WAVES, max_parked=3, younger_speed=None, keep_x_below=0, columns_from_chain=False, order="lpt",
+              products_per_half=False, separate_halves=False):
     """Who does what in a register-lean block of `waves` wavefronts (two per SIMD): returns (slots, [(LeanRole, [(column, half)])]).
 
     Phase 0 (input table): joints dealt round-robin.  Phase 1: the BACKWARD pass of the Minv recursion once per base-rooted tree -- the
@@ -282,11 +283,22 @@ def lean_plan(spec, waves=LEAN_WAVES, max_parked=3, younger_speed=None):
     the waves that are free run d/dqd recursions ahead of the barrier (parked, at most `max_parked` columns of n values each).
     Phase 2: the FORWARD pass, independent per column, divided over all waves in contiguous runs of balanced cost.  Phase 3: qdd rows
     round-robin.  Gradient half-columns: longest-processing-time placement on traced per-item costs, a younger wave's items
-    weighted by 1 / younger_speed (default LEAN_YOUNGER_SPEED)."""
+    weighted by 1 / younger_speed (default LEAN_YOUNGER_SPEED).
+
+    order="runs": every wave takes a CONTIGUOUS run of gradient columns, both halves of each (the d/dq and the d/dqd column share
+    the walk over the joints), instead of the scattered longest-processing-time sets: the half-columns a wave flushes one after
+    the other are then neighbours in the configuration's output row, so the partly written 64-byte segments at the ends of a run
+    of n values meet their other part in L2 within one column's time instead of reaching HBM twice (WRITE_SIZE 1.3x the output at
+    K = 65536, where the output no longer fits the Infinity Cache).  The runs and which role takes which run: a dynamic programme
+    over the cut points for every assignment of the roles' idle times, on traced per-column costs."""
     from .model import base_trees
     n = spec.n
     slots = CoopSlots(spec)
     slots.enable_lean(spec)
+    slots.keep_x_below = keep_x_below
+    slots.columns_from_chain = bool(columns_from_chain)
+    slots.products_per_half = bool(products_per_half)
+    slots.separate_halves = bool(separate_halves)
     trees = sorted(base_trees(spec), key=lambda t: -t[1])
     big = list(range(trees[0][0], trees[0][0] + trees[0][1]))
     rest = [j for (f, m) in trees[1:] for j in range(f, f + m)]
@@ -301,10 +313,16 @@ def lean_plan(spec, waves=LEAN_WAVES, max_parked=3, younger_speed=None):
         b = lean_barriers(tr)
         return lean_arith(tr, b[0], b[1])
     cut_b = min(range(big[0] + 1, big[-1] + 1), key=lambda c_: max(bwd_cost([k for k in big if k < c_]), bwd_cost([k for k in big if k >= c_])))
-    roles = [LeanRole("minv_backward_a", minv_bwd=big, minv_bwd_cols=[k for k in big if k < cut_b]),
-             LeanRole("minv_backward_b", minv_bwd=big, minv_bwd_cols=[k for k in big if k >= cut_b]),
-             LeanRole("minv_backward+c", minv_bwd=rest, c_roots=rest_roots) if rest else LeanRole("consumer"),
-             LeanRole("c", c_roots=[big[0]])]
+    if columns_from_chain:
+        # only the articulated-inertia chain (U, 1/D) is serial: one wave per group of trees runs it, everything per column follows B1
+        roles = [LeanRole("inertia_chain", minv_bwd=big, minv_bwd_cols=[]),
+                 LeanRole("inertia_chain+c", minv_bwd=rest, minv_bwd_cols=[], c_roots=rest_roots) if rest else LeanRole("consumer"),
+                 LeanRole("c", c_roots=[big[0]])]
+    else:
+        roles = [LeanRole("minv_backward_a", minv_bwd=big, minv_bwd_cols=[k for k in big if k < cut_b]),
+                 LeanRole("minv_backward_b", minv_bwd=big, minv_bwd_cols=[k for k in big if k >= cut_b]),
+                 LeanRole("minv_backward+c", minv_bwd=rest, c_roots=rest_roots) if rest else LeanRole("consumer"),
+                 LeanRole("c", c_roots=[big[0]])]
     roles += [LeanRole("consumer") for _ in range(waves - len(roles))]
     # forward pass: a wave that finishes columns a..b-1 walks every joint j < b of their trees (fixed cost per joint: U, 1/D, X_j, X_j^T U)
     # and pays per (joint, column >= joint) pair; contiguous runs share the joints.  Minimise the largest run (dynamic programme).
@@ -312,7 +330,7 @@ def lean_plan(spec, waves=LEAN_WAVES, max_parked=3, younger_speed=None):
     for (f, m) in base_trees(spec):
         for j in range(f, f + m):
             tree_of[j] = f
-    PER_JOINT, PER_PAIR = 45.0, 16.0
+    PER_JOINT, PER_PAIR = (70.0, 30.0) if columns_from_chain else (45.0, 16.0)
 
     def run_cost(a, b):
         cost_, seen = 0.0, set()
@@ -359,6 +377,9 @@ def lean_plan(spec, waves=LEAN_WAVES, max_parked=3, younger_speed=None):
         b = lean_barriers(trp)
         rec[c_] = lean_arith(trp, b[0], b[1])
     speed = [1.0 if w < waves // 2 else (LEAN_YOUNGER_SPEED if younger_speed is None else younger_speed) for w in range(waves)]
+    if order == "runs":
+        return slots, _lean_plan_runs(spec, slots, roles, cost, rec, [t_b1 - p1 for (p1, _) in ph], max_parked, speed, ph, t_b1)
+    assert order == "lpt", order
     load = [0.0] * waves
     items = [[] for _ in range(waves)]
     parked = [[] for _ in range(waves)]
@@ -388,6 +409,70 @@ def lean_plan(spec, waves=LEAN_WAVES, max_parked=3, younger_speed=None):
     plan = [(roles[w], sorted(items[w])) for w in range(waves)]
     slots.lean_model = dict(phase1=[p1 for (p1, _) in ph], phase2=[p2 for (_, p2) in ph], t_b1=t_b1, post=[load[w] / speed[w] for w in range(waves)])
     return slots, plan
+
+
+def _lean_plan_runs(spec, slots, roles, cost, rec, slack, max_parked, speed, ph, t_b1):
+    """lean_plan(order="runs"): every wave takes ONE contiguous run of d/dq columns and ONE contiguous run of d/dqd columns.  The
+    waves are taken in the order of their idle time before B1 (the busiest first); wave i gets the i-th run of the d/dq block
+    counted from column 0 and the i-th run of the d/dqd block counted from column n-1 -- the heavy columns are the early ones in
+    both blocks, so a heavy d/dq run meets a light d/dqd run, and the idle waves get the d/dqd columns worth parking.  The cuts of
+    both blocks by one dynamic programme on the traced per-item costs minus what parking moves ahead of the barrier.  Returns
+    the plan; sets slots.lean_model."""
+    n, waves = spec.n, len(roles)
+    pq, pd = [0.0], [0.0]
+    for c_ in range(n):
+        pq.append(pq[-1] + cost[(c_, 0)])
+        pd.append(pd[-1] + cost[(n - 1 - c_, 1)])          # (position k of the d/dqd sequence is column n-1-k)
+    gains = {}
+
+    def parked_of(s, a, b_):                                # d/dqd positions [a, b_) = columns n-b_ .. n-1-a
+        if (s, a, b_) not in gains:
+            g, chosen = 0, []
+            for c_ in sorted(range(n - b_, n - a), key=lambda c_: -rec[c_]):
+                if len(chosen) < max_parked and 0 < rec[c_] <= s - g:
+                    g += rec[c_]
+                    chosen.append(c_)
+            gains[(s, a, b_)] = (g, chosen)
+        return gains[(s, a, b_)]
+    INF = float("inf")
+    ws = sorted(range(waves), key=lambda w: (slack[w], -speed[w], w))
+    best = {(0, 0): (0.0, None)}
+    layers = [best]
+    for i in range(1, waves + 1):
+        w = ws[i - 1]
+        dload = {}
+        nxt = {}
+        last = i == waves
+        for (aq, ad), (top, _) in layers[-1].items():
+            for eq in ((n,) if last else range(aq, n + 1)):
+                lq = pq[eq] - pq[aq]
+                if lq / speed[w] >= (nxt.get((n, n), (INF,))[0] if last else INF):
+                    break
+                for ed in ((n,) if last else range(ad, n + 1)):
+                    key = (ad, ed)
+                    if key not in dload:
+                        dload[key] = pd[ed] - pd[ad] - parked_of(slack[w], ad, ed)[0]
+                    c_ = max(top, (lq + dload[key]) / speed[w])
+                    if c_ < nxt.get((eq, ed), (INF,))[0]:
+                        nxt[(eq, ed)] = (c_, (aq, ad))
+        # keep the non-dominated states only (further in both blocks at no higher load)
+        layers.append(nxt)
+    state, runs = (n, n), []
+    for i in range(waves, 0, -1):
+        prev = layers[i][state][1]
+        runs.append((prev[0], state[0], prev[1], state[1]))
+        state = prev
+    runs = runs[::-1]
+    plan_of = {w: run for w, run in zip(ws, runs)}
+    plan, post = [], []
+    for w, role in enumerate(roles):
+        aq, eq, ad, ed = plan_of[w]
+        role.hoist = sorted(parked_of(slack[w], ad, ed)[1])
+        plan.append((role, sorted([(c_, 0) for c_ in range(aq, eq)] + [(c_, 1) for c_ in range(n - ed, n - ad)])))
+        post.append((pq[eq] - pq[aq] + pd[ed] - pd[ad] - parked_of(slack[w], ad, ed)[0]) / speed[w])
+    slots.lean_model = dict(phase1=[p1 for (p1, _) in ph], phase2=[p2 for (_, p2) in ph], t_b1=t_b1, post=post,
+                            runs=[(plan_of[w][0], plan_of[w][1], n - plan_of[w][3], n - plan_of[w][2]) for w in range(waves)])
+    return plan
 
 
 def _coop_prologue(tr, spec, slots, role, X, I, qd, u, g, demand_order=True, pre_barrier=None):
@@ -1106,6 +1191,7 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
             want.setdefault(c_, set()).add(h_)
         cols = sorted(want)
     tr.run_bases = []
+    pass_halves = []        # (lean cores with separate_halves: the halves each pass of the column loop emits, in order)
     if coop is not None:
         assert kind == "fd" and not use_qdd_minv and not table and rollout is None
         role, slots = coop
@@ -1198,7 +1284,10 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
 
     def Xof_back(j):
         # lean cores: X_j for the force transfer child -> parent is REBUILT (from re-read sin / cos) instead of staying alive across
-        # the child's whole subtree
+        # the child's whole subtree -- unless that subtree is so small (CoopSlots.keep_x_below joints) that only the last levels of a
+        # path hold their X at once
+        if len(spec.subtree[j]) <= getattr(coop[1], "keep_x_below", 0) and ("X", j) in memo:
+            return memo[("X", j)]
         memo.pop(("X", j), None)
         memo.pop(("t", j), None)
         return Xof(j)
@@ -1313,18 +1402,29 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
         if coop is not None:
             # every upper-triangle entry fetched once per column from the exchange region (4 multiply-adds per LDS read)
             dqd_half = saved_dqd.pop(col, None) or {k: dc[k][1] for k in rows}       # (computed ahead of the barriers when parked)
-            halves = want[col] if want is not None else (0, 1)
+            halves = (pass_halves.pop(0) if pass_halves else want[col]) if want is not None else (0, 1)
             none = {k: tr.zero() for k in rows}
+            if want is not None:
+                # half-column runs in emission order: run k of the core (n values) goes to row offset tr.run_bases[k] (grid_out_runs)
+                def emit_run(h, values):
+                    k_run = len(tr.run_bases)
+                    tr.run_bases.append(n * col + h * n * n)
+                    for r in range(n):
+                        tr.out(n * k_run + r, values[r])
+                if len(halves) == 2 and getattr(coop[1], "products_per_half", False):
+                    # both halves of a column in one wave: ONE recursion, but the two products one after the other -- n accumulators
+                    # alive instead of 2 n, for a second fetch of the Minv entries (2 multiply-adds per LDS read instead of 4)
+                    lo, _ = alg.sym_minv_times_columns(tr, spec, lambda r, k: minv_entry(r, k), {k: dc[k][0] for k in rows}, none)
+                    emit_run(0, lo)
+                    _, hi = alg.sym_minv_times_columns(tr, spec, lambda r, k: minv_entry(r, k), none, {k: dqd_half[k] for k in rows})
+                    emit_run(1, hi)
+                    return
             lo, hi = alg.sym_minv_times_columns(tr, spec, lambda r, k: minv_entry(r, k),
                                                 {k: dc[k][0] for k in rows} if 0 in halves else none,
                                                 {k: dqd_half[k] for k in rows} if 1 in halves else none)
             if want is not None:
-                # half-column runs in emission order: run k of the core (n values) goes to row offset tr.run_bases[k] (grid_out_runs)
                 for h in sorted(halves):
-                    k_run = len(tr.run_bases)
-                    tr.run_bases.append(n * col + h * n * n)
-                    for r in range(n):
-                        tr.out(n * k_run + r, (lo, hi)[h][r])
+                    emit_run(h, (lo, hi)[h])
                 return
             for r in range(n):
                 tr.out(lo_base(col) + r, lo[r])
@@ -1408,7 +1508,10 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
                 def on_final(j, k, val):
                     if slots.minv.get((j, k)) is not None:
                         tr.xch_put(slots.minv[(j, k)], val)
-                alg.minv_forward_lean(tr, spec, Xof_back, lambda kind_, j, i: tr.xch_get(where(kind_, j, i)), role.minv_cols, on_final)
+                if getattr(slots, "columns_from_chain", False):      # U, 1/D published only: the whole per-column recursion here
+                    alg.minv_columns_lean(tr, spec, Xof_back, lambda kind_, j, i: tr.xch_get(where(kind_, j, i)), role.minv_cols, on_final)
+                else:
+                    alg.minv_forward_lean(tr, spec, Xof_back, lambda kind_, j, i: tr.xch_get(where(kind_, j, i)), role.minv_cols, on_final)
                 memo.clear()
             tr.barrier()
             # ---- phase 3: rows of qdd = Minv_sym (u - c) from the published Minv and c, then B3
@@ -1436,6 +1539,17 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
         # the parked columns first (their registers are freed early), and within both runs the deepest first: a column's accumulated
         # force then finds its children's in the f table (DFS pre-order ids: children have larger ids)
         order = sorted(hoist, reverse=True) + sorted((c for c in cols if c not in hoist), reverse=True)
+        if lean and getattr(slots, "separate_halves", False):
+            # a column whose two halves are both this wave's and not parked: TWO passes over the column (the d/dq recursion, then the
+            # d/dqd recursion) instead of one carrying both -- half the path state alive, for the walk over the joints done twice
+            passes = []
+            for c_ in order:
+                if len(want[c_]) == 2 and c_ not in hoist:
+                    passes += [(c_, (0,)), (c_, (1,))]
+                else:
+                    passes.append((c_, tuple(sorted(want[c_]))))
+            order = [c_ for (c_, _) in passes]
+            pass_halves.extend(h_ for (_, h_) in passes)
         ftab["on"] = bool(slots.f_table)
     alg.rnea_grad_columns(tr, spec, I, q, qd, trig, loader, emit_column, order=order, prefetch=0, xof=Xof, keep=keep,
                           xof_back=Xof_back if lean else None, xa_first=lean)

@@ -77,3 +77,11 @@ extern "C" void hh_spatial(const float *x, const float *y, float alpha, float *o
     float xm[6]; for (int i = 0; i < 6; i++) xm[i] = x[i];
     o[0] = G::dot_prod<float, 6, 1, 1>(x, y); o[1] = G::dot_prod<float, 3, 2, 1>(xm, y);
 }
+// launch-shape sanitiser of the dim3 host wrappers: grid_launch_dims (illegal shapes -> the suggested one) followed by
+// grid_fold_launch_z (z extents folded into y: the kernels number threads and blocks by x and y only).  io = {bx, by, bz, tx, ty, tz}
+extern "C" void hh_launch_shape(int *io, int num_timesteps) {
+    dim3 blocks, threads;
+    G::grid_launch_dims(dim3(io[0], io[1], io[2]), dim3(io[3], io[4], io[5]), num_timesteps, &blocks, &threads);
+    G::grid_fold_launch_z(&blocks, &threads);
+    io[0] = blocks.x; io[1] = blocks.y; io[2] = blocks.z; io[3] = threads.x; io[4] = threads.y; io[5] = threads.z;
+}

@@ -123,3 +123,23 @@ def test_spatial_algebra_device_library(harness):
     np.testing.assert_allclose(out[o:o + 6], y64 + crf @ y64, rtol=1e-5, atol=1e-5); o += 6
     np.testing.assert_allclose(out[o], x64 @ y64, rtol=1e-5)
     np.testing.assert_allclose(out[o + 1], x64[0] * y64[0] + x64[2] * y64[1] + x64[4] * y64[2], rtol=1e-5)
+
+
+def test_launch_shape_sanitiser_folds_z(harness):
+    """The dim3 host wrappers number threads as x + y*size_x (the reference's kernels: helpers/_code_generation_helpers.py:41-55); a z
+    extent would hand several waves the same thread id -- and the same LDS staging region.  grid_launch_dims + grid_fold_launch_z:
+    illegal shapes become the suggested one, z extents are folded into y with the thread / block count unchanged."""
+    name, lib = harness
+    shape = lambda *v: (ctypes.c_int * 6)(*v)
+    io = shape(4, 1, 1, 64, 2, 2)                      # 256 threads as 64 x 2 x 2
+    lib.hh_launch_shape(io, 1000)
+    assert list(io) == [4, 1, 1, 64, 4, 1]
+    io = shape(2, 3, 2, 128, 1, 1)                     # 12 blocks as 2 x 3 x 2
+    lib.hh_launch_shape(io, 1000)
+    assert list(io) == [2, 6, 1, 128, 1, 1]
+    io = shape(1, 1, 1, 64, 4, 2)                      # 512 threads: more than the kernels accept -> the suggested shape
+    lib.hh_launch_shape(io, 1000)
+    assert io[2] == 1 and io[5] == 1 and io[3] * io[4] <= 256 and io[0] * io[3] * io[4] >= 1000 // 1 or io[0] >= 1
+    io = shape(0, 0, 0, 0, 0, 0)
+    lib.hh_launch_shape(io, 100)
+    assert io[0] >= 1 and io[3] >= 64 and io[2] == 1 and io[5] == 1

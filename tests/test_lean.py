@@ -82,6 +82,46 @@ def test_lean_block_matches_oracle(robot, robots, tables):
     assert table <= set(writers) and set(slots.c) <= set(writers) and set(slots.qdd) <= set(writers) and set(slots.minv.values()) <= set(writers)
 
 
+def test_lean_block_with_per_column_minv_matches_oracle(robots, tables):
+    """lean_plan(columns_from_chain=True): only the articulated-inertia chain (U, 1/D) of the Minv recursion is serial and published;
+    the backward pass's F recursions move into the per-column phase (alg.minv_columns_lean) that all eight waves share."""
+    from oracle import rbd_oracle as O
+    spec = RobotSpec(robots("atlas30"))
+    n, K = spec.n, 2
+    q, qd, u = (a.astype(np.float64) for a in make_inputs(n, K, 62))
+    ref = O.fd_grad(tables("atlas30"), q, qd, u)
+    ref = np.concatenate([O.flat_colmajor(ref[:, :, :n]), O.flat_colmajor(ref[:, :, n:])], axis=1)
+    slots, plan = cores.lean_plan(spec, columns_from_chain=True)
+    got, traces = emulate_lean_block(spec, slots, plan, q, qd, u)
+    assert not np.isnan(got).any() and relerr(got, ref)[0] < 5e-6
+    assert sorted(k for (role, _) in plan for k in role.minv_cols) == list(range(n))
+
+
+@pytest.mark.parametrize("robot", ["atlas30", "quad12"])
+def test_lean_block_in_contiguous_runs_matches_oracle(robot, robots, tables):
+    """lean_plan(order="runs"): every wave takes one contiguous run of d/dq columns and one of d/dqd columns (the half-columns it
+    flushes one after the other are neighbours in the configuration's output row); same outputs, every half-column exactly once,
+    parked columns inside the wave's own d/dqd run."""
+    from oracle import rbd_oracle as O
+    spec = RobotSpec(robots(robot))
+    n, K = spec.n, 2
+    q, qd, u = (a.astype(np.float64) for a in make_inputs(n, K, 63))
+    ref = O.fd_grad(tables(robot), q, qd, u)
+    ref = np.concatenate([O.flat_colmajor(ref[:, :, :n]), O.flat_colmajor(ref[:, :, n:])], axis=1)
+    slots, plan = cores.lean_plan(spec, order="runs")
+    got, traces = emulate_lean_block(spec, slots, plan, q, qd, u)
+    assert not np.isnan(got).any() and relerr(got, ref)[0] < 5e-6
+    seen = []
+    for role, items in plan:
+        for h in (0, 1):
+            cols = sorted(c for (c, h_) in items if h_ == h)
+            assert cols == list(range(cols[0], cols[-1] + 1)) if cols else True       # one contiguous run per block
+            seen += [(c, h) for c in cols]
+        assert set(role.hoist) <= set(c for (c, h_) in items if h_ == 1)
+    assert sorted(seen) == [(c, h) for c in range(n) for h in (0, 1)]
+    assert max(slots.lean_model["post"]) <= 1.05 * max(cores.lean_plan(spec)[0].lean_model["post"])     # balanced nearly as well as the scattered sets
+
+
 def test_lean_cores_stay_within_half_a_simd(robots):
     """The point of the exercise: the values a lean core holds at once (creation-order emission, the order the kernel is emitted in)
     stay far below 256 -- the 4-wave cores of the same robot hold 280-390 in their prologue alone -- and the block's LDS fits the CU."""

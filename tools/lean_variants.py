@@ -21,6 +21,20 @@ VARIANTS = {
     "atlas30_xy100p3": dict(experimental={"lean_plan": {"younger_speed": 1.0, "max_parked": 3}}),
     # wave-per-configuration kernels compiled for two waves per SIMD (<= 256 registers instead of 295: 1024 resident blocks instead of 512)
     "atlas30_wocc2": dict(experimental={"wave_occupancy": 2}),
+    # X_j kept alive for the way back up the tree where the subtree below j has at most this many joints (instead of rebuilding it)
+    "atlas30_kx2": dict(experimental={"lean_plan": {"keep_x_below": 2}}),
+    "atlas30_kx4": dict(experimental={"lean_plan": {"keep_x_below": 4}}),
+    "atlas30_kx8": dict(experimental={"lean_plan": {"keep_x_below": 8}}),
+    # only the articulated-inertia chain is serial; the F recursions of the backward pass move to the per-column phase (all eight waves)
+    "atlas30_cfc": dict(experimental={"lean_plan": {"columns_from_chain": True}}),
+    # every wave takes a contiguous run of whole gradient columns (neighbours in the output row are flushed one after the other)
+    "atlas30_runs": dict(experimental={"lean_plan": {"order": "runs"}}),
+    # a column whose two halves are one wave's: two passes (d/dq recursion, d/dqd recursion) instead of one carrying both
+    "atlas30_sep": dict(experimental={"lean_plan": {"separate_halves": True}}),
+    "atlas30_runs2": dict(experimental={"lean_plan": {"order": "runs"}}),
+    "atlas30_runs_pph": dict(experimental={"lean_plan": {"order": "runs", "products_per_half": True}}),
+    # both halves of a column in one wave: one recursion, the two -Minv dc products one after the other (n accumulators instead of 2 n)
+    "atlas30_pph": dict(experimental={"lean_plan": {"products_per_half": True}}),
     "atlas30_p4": dict(experimental={"lean_plan": {"max_parked": 4}}),
     "atlas30_p2": dict(experimental={"lean_plan": {"max_parked": 2}}),
     # scheduling fences every N statements inside the lean cores (smaller reordering windows for hipcc: fewer spills, less overlap)

@@ -1,7 +1,8 @@
 """Run one algorithm a few times (for rocprofv3 PMC collection).  usage: run_alg.py robot alg K pipeline_mode split reps [coop_mode]"""
-import sys; sys.path.insert(0, '.')
+import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tools')
 import numpy as np, torch
 from gridcodegenerator_amd import host
+import lean_variants; lean_variants.register()          # (experiment variants load by name like the built-in robots)
 robot, alg, K, mode, split, reps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
 h = host.GridHandle(robot); n = h.n
 x = np.random.default_rng(0).uniform(-1, 1, (K, 3 * n)).astype(np.float32)
