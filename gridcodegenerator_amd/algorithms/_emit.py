@@ -123,6 +123,12 @@ class AlgorithmEmitMixin:
                 return "in.m_put(%s, (T)(%s));" % (dst[5:], val)
             if dst == "wsync":
                 return "GRID_SCHED_FENCE(); in.sync(); GRID_SCHED_FENCE();"
+            if dst.startswith("piece:"):        # (emit/cores.py: AlignedPieces -- value `pos` of a piece of `len` values)
+                _, length, pos = dst.split(":")
+                return "out.template put_at<%s>(%s, (T)(%s));" % (length, pos, val)
+            if dst.startswith("flush:"):
+                _, length, base = dst.split(":")
+                return "out.template flush<%s>(%s);%s" % (length, base, fence_after_store())
         return "out.put(%s, (T)(%s));%s" % (dst, val, fence_after_store())
 
     def _emit_load(self, dst, src, total, stride, piece=MAX_IN_PIECE, rows=False):
@@ -982,6 +988,10 @@ class AlgorithmEmitMixin:
         launches = [
             "const T *d_in = USE_COMPRESSED_MEM ? hd_data->d_q_qd : hd_data->d_q_qd_u;",
             "if (USE_QDD_FLAG) {inverse_dynamics_gradient_kernel<T>@L(hd_data->d_dc_du,d_in,stride_q_qd,hd_data->d_qdd,d_robotModel,gravity,num_timesteps);}",
+            # large robots at qdd = 0: the register-lean tile-cooperative kernel where the generator emitted one (ID_DU_LEAN_AUTO_MIN_TILES:
+            # from how many tiles on) -- same outputs, blocks/threads then unused
+            "else if (ID_DU_LEAN_AUTO_MIN_TILES > 0 && (num_timesteps + GRID_WAVE_SIZE - 1)/GRID_WAVE_SIZE >= ID_DU_LEAN_AUTO_MIN_TILES && "
+            "inverse_dynamics_gradient_lean_launch<T>(hd_data->d_dc_du,d_in,stride_q_qd,d_robotModel,gravity,num_timesteps,0,@S)) {}",
             "else              {inverse_dynamics_gradient_kernel<T>@L(hd_data->d_dc_du,d_in,stride_q_qd,d_robotModel,gravity,num_timesteps);}"]
         post = ["// finally transfer the result back",
                 "gpuErrchk(hipMemcpy(hd_data->h_dc_du,hd_data->d_dc_du,NUM_JOINTS*2*NUM_JOINTS*num_timesteps*sizeof(T),hipMemcpyDeviceToHost));",
@@ -1014,6 +1024,7 @@ class AlgorithmEmitMixin:
                                        ("q_qd", 2 * n, "stride_q_qd"), True)
         else:
             self._emit_no_pipeline("ID_DU", "inverse_dynamics_gradient", "dc_du", ("q_qd", 2 * n, "stride_q_qd"))
+        self.gen_inverse_dynamics_gradient_lean_decl()
         self.gen_inverse_dynamics_gradient_host()
 
     # ------------------------------------------------------------------------------------------
@@ -1857,9 +1868,13 @@ class AlgorithmEmitMixin:
             plan = [(role, items if w < W // 2 else []) for w, (role, items) in enumerate(plan)]
         elif self.lean_probe == "younger":
             plan = [(role, items if w >= W // 2 else []) for w, (role, items) in enumerate(plan)]
-        stage = WAVE * n                             # per wave: one input piece / one gradient half-column per flush
+        # per wave: one gradient half-column per flush (or one piece of at most 32 values at a pitch of 34: AlignedPieces); before
+        # the first flush the staging regions park U, 1/D of the Minv recursion (7 n words per lane) and u - c (n more, lean_umc)
+        stage = WAVE * (34 if getattr(slots, "aligned_flush", False) else n)
+        if not self.lean_row_loads:
+            stage = max(stage, WAVE * n)             # (the staged input load goes through the same region, n values at a time)
         lds_elems = W * stage + WAVE * slots.count
-        if 4 * lds_elems > 160 * 1024 or 7 * n > W * (stage // WAVE):
+        if 4 * lds_elems > 160 * 1024 or (8 if slots.lean_umc else 7) * n > W * (stage // WAVE):
             self.note("no register-lean 8-wave tile-cooperative kernel (FD_DU_LEAN_WAVES = 0): exchange region + input table + 8 staging "
                       "regions need %d KB of the CU's 160 KB of LDS" % (4 * lds_elems // 1024))
             return None
@@ -1916,7 +1931,7 @@ class AlgorithmEmitMixin:
             tr = cores.core_gradient_recompute(self.spec, "fd", cols=items, coop=(role, slots))
             self._emit_core(cname, "Register-lean tile-cooperative forward-dynamics gradient, wave %d of %d: %r; gradient half-columns (column, 0 = d/dq | 1 = d/dqd) %s"
                             % (w, W, role, list(items)), tr, order="creation", read_ahead=self.lean_read_ahead)
-            names.append((cname, list(tr.run_bases)))
+            names.append((cname, list(tr.run_bases), any(isinstance(d, str) and d.startswith("flush:") for (d, _) in tr.outputs)))
         n_out = self.io_layout["FD_DU"]["n_out"]
         self.kernel_instances.append("__global__ void @NS::forward_dynamics_gradient_kernel_coop8<T>(T *, const T *, const int, "
                                      "const @NS::robotModel<T> *, const T, const int);")
@@ -1944,15 +1959,22 @@ class AlgorithmEmitMixin:
             "for (int k0 = bid*GRID_WAVE_SIZE; k0 < NUM_TIMESTEPS; k0 += nblocks*GRID_WAVE_SIZE){",
         ])
         self.indent_level += 1
-        self.gen_add_code_line("T s_q_qd_u[%d];" % (3 * n))
-        self._emit_load("s_q_qd_u", "d_q_qd_u", 3 * n, "stride_q_qd_u", piece)
+        if self.lean_row_loads:
+            # every lane reads the few inputs its wave needs (its share of the input table, u of the bias-torque joints) straight from
+            # its configuration's row: 8 waves staging all 3n inputs each was ~300 instructions per wave for ~12 values used
+            self.gen_add_code_line("const T *s_q_qd_u = d_q_qd_u + (size_t)min(k0 + it.lane, NUM_TIMESTEPS - 1)*stride_q_qd_u;")
+        else:
+            self.gen_add_code_line("T s_q_qd_u[%d];" % (3 * n))
+            self._emit_load("s_q_qd_u", "d_q_qd_u", 3 * n, "stride_q_qd_u", piece)
         self.gen_add_code_line("const unsigned xb = (unsigned)reinterpret_cast<unsigned long long>(s_xch) + (unsigned)sizeof(T)*it.lane;")
         self.gen_add_code_line("const grid_in_lean<T> in = {s_q_qd_u, s_q_qd_u + %d, s_q_qd_u + %d, s_xch, it.lane, xb, xb + 256u*GRID_WAVE_SIZE*(unsigned)sizeof(T), "
                                "xb - 256u*GRID_WAVE_SIZE*(unsigned)sizeof(T)};" % (n, 2 * n))
         self.gen_add_code_line("switch (it.wave_in_block){", True)
-        for w, (cname, bases) in enumerate(names):
+        for w, (cname, bases, pieces) in enumerate(names):
             self.gen_add_code_line("case %d: {" % w, True)
-            if bases:
+            if pieces:
+                self.gen_add_code_line("grid_out_pieces<T,%d> out = {s_wave, d_df_du, k0, it.lane, it.W, NUM_TIMESTEPS};" % n_out)
+            elif bases:
                 self.gen_add_code_line("grid_out_runs<T,%d,%d,%s> out = {s_wave, d_df_du, k0, it.lane, it.W, NUM_TIMESTEPS};"
                                        % (n_out, n, ",".join(str(b) for b in bases)))
             else:
@@ -1993,6 +2015,148 @@ class AlgorithmEmitMixin:
         self.gen_add_code_line("__host__ inline")
         self.gen_add_code_line("bool forward_dynamics_gradient_lean_attributes(hipFuncAttributes *attr) {", True)
         self.gen_add_code_line("gpuErrchk(hipFuncGetAttributes(attr, reinterpret_cast<const void *>(&forward_dynamics_gradient_kernel_coop8<T>))); return true;")
+        self.gen_add_end_function()
+
+    # ------------------------------------------------------------------------------------------
+    # register-lean tile-cooperative INVERSE-dynamics gradient (large robots, qdd = 0 variant)
+    # ------------------------------------------------------------------------------------------
+    def _lean_id_prepare(self):
+        """(slots, plan, stage, lds_elems) of `inverse_dynamics_gradient_kernel_coop8`, or None (same conditions as the forward-dynamics
+        kernel's: large robot, fp32, recomputing schedule)."""
+        if hasattr(self, "_lean_id_cache"):
+            return self._lean_id_cache
+        n, W = self.spec.n, cores.LEAN_WAVES
+        self._lean_id_cache = None
+        if n <= 12 or self.precision != "fp32" or self.grad_schedule != "recompute":
+            return None
+        slots, plan = cores.lean_plan_id(self.spec, False, W)
+        stage = WAVE * 34
+        lds_elems = W * stage + WAVE * slots.count
+        if 4 * lds_elems > 160 * 1024:
+            self.note("no register-lean 8-wave inverse-dynamics-gradient kernel (ID_DU_LEAN_WAVES = 0): input table + 8 staging regions need "
+                      "%d KB of the CU's 160 KB of LDS" % (4 * lds_elems // 1024))
+            return None
+        self._lean_id_cache = (slots, plan, stage, lds_elems)
+        return self._lean_id_cache
+
+    LEAN_ID_LAUNCH_SIG = ("bool inverse_dynamics_gradient_lean_launch(T *d_dc_du, const T *d_q_qd, const int stride_q_qd, const robotModel<T> *d_robotModel, "
+                          "const T gravity, const int num_timesteps, int tile_blocks, hipStream_t stream)")
+
+    def gen_inverse_dynamics_gradient_lean_decl(self):
+        """Forward declaration of the register-lean inverse-dynamics-gradient launcher and its constants, ahead of the reference-named host
+        wrapper that dispatches it; the kernel itself is emitted last (gen_inverse_dynamics_gradient_lean).  A documented block of its
+        own: the object-cache keys of the other kernels do not move (host.kernel_dependency_hashes)."""
+        prep = self._lean_id_prepare()
+        W = cores.LEAN_WAVES
+        self.gen_add_func_doc("Launch the register-lean tile-cooperative inverse-dynamics-gradient kernel, qdd = 0 (declaration; defined with the kernel at the end of the header)",
+                              ["returns false when this robot / arithmetic has no such kernel (ID_DU_LEAN_WAVES == 0)"], [], None)
+        self.gen_add_code_lines(["template <typename T>", "__host__ inline", self.LEAN_ID_LAUNCH_SIG + ";"])
+        if prep is None:
+            self.gen_add_code_line("const int ID_DU_LEAN_WAVES = 0; // no register-lean inverse-dynamics-gradient kernel for this robot / arithmetic")
+            self.gen_add_code_line("const int ID_DU_LEAN_AUTO_MIN_TILES = 0;")
+        else:
+            slots, plan, stage, lds_elems = prep
+            self.gen_add_code_line("const int ID_DU_LEAN_WAVES = %d; // wavefronts per block of inverse_dynamics_gradient_kernel_coop8 (block = %d threads, one tile)" % (W, W * WAVE))
+            self.gen_add_code_line("const int ID_DU_LEAN_AUTO_MIN_TILES = %d; // automatic choice of that kernel from this many tiles on (0: only on request)" % self.lean_id_auto_min_tiles)
+            self.gen_add_code_line("const int ID_DU_LEAN_SHARED_MEM_COUNT = %d; // dynamic LDS in T elements: %d staging regions of %d + %d table slots x 64 lanes"
+                                   % (lds_elems, W, stage, slots.count))
+        self.gen_add_code_line("")
+
+    def gen_inverse_dynamics_gradient_lean(self, use_thread_group=False):
+        """`inverse_dynamics_gradient_kernel_coop8` (qdd = 0): the inverse-dynamics gradient of a large robot on the register-lean block
+        of the forward-dynamics kernel -- eight wavefronts per tile of 64 configurations, two per SIMD, at most 256 registers each; a
+        block-shared input table (sin q, cos q, qd), ONE barrier, then every wave's contiguous runs of gradient half-columns, cut at the
+        32-byte sectors of the output row (cores.lean_plan_id, cores.AlignedPieces).  Replaces the 4-way column split for batches that
+        fill the chip (each of its waves owned a SIMD, staged all inputs and spilled).  Reference mapping being replaced:
+        algorithms/_inverse_dynamics_gradient.py:199-246,501-540 (threads of a block = gradient columns)."""
+        n, W = self.spec.n, cores.LEAN_WAVES
+        prep = self._lean_id_prepare()
+        if prep is None:
+            self.gen_add_func_doc("No register-lean inverse-dynamics-gradient kernel for this robot / arithmetic", [], [], None)
+            self.gen_add_code_lines(["template <typename T>", "__host__ inline",
+                                     "bool inverse_dynamics_gradient_lean_launch(T *, const T *, const int, const robotModel<T> *, const T, const int, int, hipStream_t) {return false;}",
+                                     "template <typename T>", "__host__ inline",
+                                     "bool inverse_dynamics_gradient_lean_attributes(hipFuncAttributes *) {return false;}", ""])
+            return
+        slots, plan, stage, lds_elems = prep
+        xch_off = W * stage
+        self.lean_id_stats = dict(plan=[(repr(r), list(items)) for (r, items) in plan], slots=slots.count, lds_bytes=4 * lds_elems, model=dict(slots.lean_model))
+        names = []
+        for w, (role, items) in enumerate(plan):
+            cname = "inverse_dynamics_gradient_lean_core_w%d" % w
+            tr = cores.core_gradient_recompute(self.spec, "id", cols=items, coop=(role, slots))
+            self._emit_core(cname, "Register-lean tile-cooperative inverse-dynamics gradient (qdd = 0), wave %d of %d: input table of joints %s; gradient "
+                            "half-columns (column, 0 = d/dq | 1 = d/dqd) %s" % (w, W, role.joints, list(items)), tr, order="creation")
+            names.append(cname)
+        n_out = self.io_layout["ID_DU"]["n_out"]
+        self.kernel_instances.append("__global__ void @NS::inverse_dynamics_gradient_kernel_coop8<T>(T *, const T *, const int, "
+                                     "const @NS::robotModel<T> *, const T, const int);")
+        self.gen_add_func_doc("Computes the gradient of inverse dynamics, qdd = 0 (register-lean tile-cooperative: %d wavefronts, two per SIMD, share each tile of 64 configurations)" % W,
+                              ["launch with EXACTLY %d threads per block and ID_DU_LEAN_SHARED_MEM_COUNT*sizeof(T) of dynamic LDS" % (W * WAVE),
+                               "(use inverse_dynamics_gradient_lean_launch); blocks grid-stride over the tiles",
+                               "LDS: [%d staging regions | input table]" % W],
+                              ["d_dc_du is the output buffer, %d values per configuration" % n_out,
+                               "d_q_qd is the input buffer, %d values read per configuration" % (2 * n),
+                               "stride_q_qd is the stride between configurations in d_q_qd",
+                               "d_robotModel is the pointer to the initialized model specific helpers on the GPU (unused: constants are baked in)",
+                               "gravity is the gravity constant", "NUM_TIMESTEPS is the number of configurations"], None)
+        self.gen_add_code_line("template <typename T, typename C = typename grid_compute<T>::type>")
+        self.gen_add_code_line("__global__ __launch_bounds__(%d)" % (W * WAVE))
+        self.gen_add_code_line("void inverse_dynamics_gradient_kernel_coop8(T *d_dc_du, const T *d_q_qd, const int stride_q_qd, "
+                               "const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS) {", True)
+        self.gen_add_code_lines([
+            "extern __shared__ __align__(16) unsigned char s_grid_dyn[];",
+            "grid_tile_iter it(NUM_TIMESTEPS);              // lane / wave bookkeeping only: the tile loop below is per BLOCK",
+            "T *s_wave = reinterpret_cast<T *>(s_grid_dyn) + it.wave_in_block*%d;" % stage,
+            "T *s_xch = reinterpret_cast<T *>(s_grid_dyn) + %d;" % xch_off,
+            "const int nblocks = grid_num_blocks();",
+            "const int bid = grid_block_id();",
+            "if (grid_block_threads() != %d){return;}    // (the launcher guarantees it; a wrong shape must not deadlock the barrier)" % (W * WAVE),
+            "for (int k0 = bid*GRID_WAVE_SIZE; k0 < NUM_TIMESTEPS; k0 += nblocks*GRID_WAVE_SIZE){",
+        ])
+        self.indent_level += 1
+        self.gen_add_code_line("const T *s_q_qd = d_q_qd + (size_t)min(k0 + it.lane, NUM_TIMESTEPS - 1)*stride_q_qd;     // every lane reads the few inputs its wave needs from its row")
+        self.gen_add_code_line("const unsigned xb = (unsigned)reinterpret_cast<unsigned long long>(s_xch) + (unsigned)sizeof(T)*it.lane;")
+        self.gen_add_code_line("const grid_in_lean<T> in = {s_q_qd, s_q_qd + %d, nullptr, s_xch, it.lane, xb, xb + 256u*GRID_WAVE_SIZE*(unsigned)sizeof(T), "
+                               "xb - 256u*GRID_WAVE_SIZE*(unsigned)sizeof(T)};" % n)
+        self.gen_add_code_line("switch (it.wave_in_block){", True)
+        for w, cname in enumerate(names):
+            self.gen_add_code_line("case %d: {" % w, True)
+            self.gen_add_code_line("grid_out_pieces<T,%d> out = {s_wave, d_dc_du, k0, it.lane, it.W, NUM_TIMESTEPS};" % n_out)
+            self.gen_add_code_line("%s<T,C>(in, out, gravity);" % cname)
+            self.gen_add_code_line("break;")
+            self.gen_add_end_control_flow()
+        self.gen_add_code_line("default: break;")
+        self.gen_add_end_control_flow()
+        self.gen_add_code_line("grid_block_sync();     // the input table and the staging regions are rewritten by the next tile")
+        self.gen_add_end_control_flow()
+        self.gen_add_end_function()
+        self.gen_add_func_doc("Launch the register-lean tile-cooperative inverse-dynamics-gradient kernel (asynchronous, on `stream`)",
+                              ["tile_blocks <= 0: one block per tile of 64 configurations (capped at 4*SUGGESTED_MAX_BLOCKS)"], [], None)
+        self.gen_add_code_line("template <typename T>")
+        self.gen_add_code_line("__host__ inline")
+        self.gen_add_code_line(self.LEAN_ID_LAUNCH_SIG + " {", True)
+        self.gen_add_code_lines([
+            "const size_t lds_bytes = (size_t)ID_DU_LEAN_SHARED_MEM_COUNT*sizeof(T);",
+            "static thread_local int configured_device = -1;        // > 64 KiB of dynamic LDS must be enabled once per device",
+            "int dev = 0; gpuErrchk(hipGetDevice(&dev));",
+            "if (lds_bytes > 65536 && configured_device != dev){",
+            "    gpuErrchk(hipFuncSetAttribute(reinterpret_cast<const void *>(&inverse_dynamics_gradient_kernel_coop8<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));",
+            "    configured_device = dev;",
+            "}",
+            "const int tiles = (num_timesteps + GRID_WAVE_SIZE - 1)/GRID_WAVE_SIZE;",
+            "if (tile_blocks <= 0 || tile_blocks > tiles){tile_blocks = tiles;}",
+            "if (tile_blocks > 4*SUGGESTED_MAX_BLOCKS){tile_blocks = 4*SUGGESTED_MAX_BLOCKS;}",
+            "inverse_dynamics_gradient_kernel_coop8<T><<<dim3(tile_blocks,1,1),dim3(%d,1,1),lds_bytes,stream>>>(d_dc_du,d_q_qd,stride_q_qd,d_robotModel,gravity,num_timesteps);" % (W * WAVE),
+            "gpuErrchk(hipGetLastError());",
+            "return true;",
+        ])
+        self.gen_add_end_function()
+        self.gen_add_func_doc("hipFuncGetAttributes of the register-lean inverse-dynamics-gradient kernel", ["returns false when this robot has none"], [], None)
+        self.gen_add_code_line("template <typename T>")
+        self.gen_add_code_line("__host__ inline")
+        self.gen_add_code_line("bool inverse_dynamics_gradient_lean_attributes(hipFuncAttributes *attr) {", True)
+        self.gen_add_code_line("gpuErrchk(hipFuncGetAttributes(attr, reinterpret_cast<const void *>(&inverse_dynamics_gradient_kernel_coop8<T>))); return true;")
         self.gen_add_end_function()
 
     def _emit_no_coop(self):

@@ -176,9 +176,10 @@ class CoopSlots:
         self.hoist_max_columns = 4       # n parked values per column stay in registers across the barriers
 
     lean = False            # see enable_lean()
+    lean_umc = False
     itab = None
 
-    def enable_lean(self, spec):
+    def enable_lean(self, spec, umc=False):
         """Register-lean cores for blocks whose waves PAIR UP on the SIMDs (8 waves per tile, <= 256 registers each; the 4-wave
         kernel's waves own a SIMD and 464 registers).  What changes in the cores (core_gradient_recompute):
           * sin q, cos q, qd (q of prismatic joints) live in a block-shared input table of the exchange region -- every wave writes the
@@ -195,11 +196,24 @@ class CoopSlots:
         self.f = {}
         self.f_table = False
         base = len(self.minv)
-        self.count = base + 2 * n               # c, qdd (one producer of qdd per row: no second share)
         self.qdd2 = None
-        self.itab = {"s": [self.count + j for j in range(n)], "c": [self.count + n + j for j in range(n)],
-                     "qd": [self.count + 2 * n + j for j in range(n)], "u": [self.count + 3 * n + j for j in range(n)]}
-        self.count += 4 * n
+        self.lean_umc = bool(umc)
+        if umc:
+            # the waves that compute the bias torques publish u - c (the only form c is used in: qdd = Minv (u - c)) and read u
+            # themselves: no u in the input table, and the n words live BELOW the region next to U and 1/D (the staging regions,
+            # idle until the first flush): 2 n slots = 15 KB less LDS for Atlas-30, which the 34-word staging rows of the
+            # sector-aligned flush need
+            self.c = [-(7 * n + 1 + j) for j in range(n)]
+            self.qdd = [base + j for j in range(n)]
+            self.count = base + n
+            self.itab = {"s": [self.count + j for j in range(n)], "c": [self.count + n + j for j in range(n)],
+                         "qd": [self.count + 2 * n + j for j in range(n)]}
+            self.count += 3 * n
+        else:
+            self.count = base + 2 * n               # c, qdd (one producer of qdd per row: no second share)
+            self.itab = {"s": [self.count + j for j in range(n)], "c": [self.count + n + j for j in range(n)],
+                         "qd": [self.count + 2 * n + j for j in range(n)], "u": [self.count + 3 * n + j for j in range(n)]}
+            self.count += 4 * n
         if any(not t for t in spec.uses_trig):
             self.itab["q"] = [self.count + j for j in range(n)]
             self.count += n
@@ -223,6 +237,52 @@ class CoopSlots:
 
 
 COOP_ROLES = ("producer", "producer2", "consumer_c", "consumer")
+
+
+class AlignedPieces:
+    """Output stream of a lean core whose half-columns arrive in runs of NEIGHBOURS of the output row (lean_plan(order="runs")): the
+    n values of a half-column are not flushed as they are -- 120 bytes at an 8-byte aligned offset: every flush leaves two partly
+    written 32-byte sectors per configuration, which the memory side writes as whole sectors (WRITE_SIZE 1.23x the output, and the
+    pure store stream of K = 65536 takes 187 us against 159 us in aligned pieces: profiles/r04/ubench_store_pieces.txt) -- but cut at
+    the sector boundaries of the row: the values past the last boundary stay in registers (at most 7) and leave with the next
+    half-column, which continues the same run.  A piece is at most 32 values; only the two ends of a run write partial sectors.
+    The row itself starts on a sector boundary when 2 n^2 is a multiple of 8 (n even); otherwise no cutting.
+
+    Emits, per piece: tr.out("piece:<len>:<pos>", value) for its values, then tr.out("flush:<len>:<row offset>", 0)."""
+
+    SECTOR = 8          # values of the storage type (float) per 32-byte sector
+    MAX_PIECE = 32      # values per piece (grid_out_pieces: staging pitch 34)
+
+    def __init__(self, tr, n, row, bases):
+        self.tr, self.n, self.bases = tr, n, list(bases)
+        self.unit = self.SECTOR if row % self.SECTOR == 0 else 1
+        self.k = 0
+        self.start, self.vals = None, []
+        self.pieces = []            # (row offset, length) of every emitted piece, in order
+
+    def push(self, base, values):
+        assert base == self.bases[self.k] and len(values) == self.n
+        self.k += 1
+        if self.vals:
+            assert self.start + len(self.vals) == base
+        else:
+            self.start = base
+        self.vals += values
+        end = base + self.n
+        ascending = self.k < len(self.bases) and self.bases[self.k] == end
+        cut = (end // self.unit) * self.unit if ascending else end
+        if cut <= self.start:
+            return                  # (nothing complete yet: everything is carried)
+        while self.start < cut:
+            length = cut - self.start
+            if length > self.MAX_PIECE:     # (the end of a run: carried values + a whole half-column -- the aligned part, then the tail)
+                length = ((self.start + self.MAX_PIECE) // self.unit) * self.unit - self.start
+            for pos in range(length):
+                self.tr.out("piece:%d:%d" % (length, pos), self.vals[pos])
+            self.tr.out("flush:%d:%d" % (length, self.start), 0.0)
+            self.pieces.append((self.start, length))
+            self.vals = self.vals[length:]
+            self.start += length
 
 
 class LeanRole:
@@ -273,8 +333,8 @@ def lean_barriers(tr):
     return [pos for (dst, _), pos in zip(tr.outputs, tr.out_pos) if dst == "barrier"]
 
 
-def lean_plan(spec, waves=LEAN_WAVES, max_parked=3, younger_speed=None, keep_x_below=0, columns_from_chain=False, order="lpt",
-              products_per_half=False, separate_halves=False):
+def lean_plan(spec, waves=LEAN_WAVES, max_parked=3, younger_speed=None, keep_x_below=0, columns_from_chain=False, order="runs",
+              products_per_half=False, separate_halves=False, umc=True, aligned_flush=True):
     """Who does what in a register-lean block of `waves` wavefronts (two per SIMD): returns (slots, [(LeanRole, [(column, half)])]).
 
     Phase 0 (input table): joints dealt round-robin.  Phase 1: the BACKWARD pass of the Minv recursion once per base-rooted tree -- the
@@ -294,11 +354,12 @@ def lean_plan(spec, waves=LEAN_WAVES, max_parked=3, younger_speed=None, keep_x_b
     from .model import base_trees
     n = spec.n
     slots = CoopSlots(spec)
-    slots.enable_lean(spec)
+    slots.enable_lean(spec, umc=umc)
     slots.keep_x_below = keep_x_below
     slots.columns_from_chain = bool(columns_from_chain)
     slots.products_per_half = bool(products_per_half)
     slots.separate_halves = bool(separate_halves)
+    slots.aligned_flush = bool(aligned_flush)
     trees = sorted(base_trees(spec), key=lambda t: -t[1])
     big = list(range(trees[0][0], trees[0][0] + trees[0][1]))
     rest = [j for (f, m) in trees[1:] for j in range(f, f + m)]
@@ -378,7 +439,8 @@ def lean_plan(spec, waves=LEAN_WAVES, max_parked=3, younger_speed=None, keep_x_b
         rec[c_] = lean_arith(trp, b[0], b[1])
     speed = [1.0 if w < waves // 2 else (LEAN_YOUNGER_SPEED if younger_speed is None else younger_speed) for w in range(waves)]
     if order == "runs":
-        return slots, _lean_plan_runs(spec, slots, roles, cost, rec, [t_b1 - p1 for (p1, _) in ph], max_parked, speed, ph, t_b1)
+        return slots, _lean_plan_runs(spec, slots, roles, cost, rec, [t_b1 - p1 for (p1, _) in ph], max_parked, speed, ph, t_b1,
+                                      prefix_parking=aligned_flush)
     assert order == "lpt", order
     load = [0.0] * waves
     items = [[] for _ in range(waves)]
@@ -411,7 +473,31 @@ def lean_plan(spec, waves=LEAN_WAVES, max_parked=3, younger_speed=None, keep_x_b
     return slots, plan
 
 
-def _lean_plan_runs(spec, slots, roles, cost, rec, slack, max_parked, speed, ph, t_b1):
+def lean_plan_id(spec, use_qdd=False, waves=LEAN_WAVES):
+    """Who does what in a register-lean block of the INVERSE-dynamics gradient (dc_du at (q, qd[, qdd]); 8 waves per tile, two per
+    SIMD): every wave writes its share of the block's input table, one barrier, then its gradient half-columns -- one contiguous
+    run of d/dq columns and one of d/dqd columns each, cut by the same dynamic programme as the forward-dynamics kernel's (no Minv,
+    no bias torques, nothing to park).  Returns (slots, [(LeanRole, [(column, half)])])."""
+    n = spec.n
+    slots = CoopSlots(spec)
+    slots.minv = {}                      # (no Minv in this kernel: the region holds the input table and, with use_qdd, qdd)
+    slots.enable_lean(spec, umc=True)
+    slots.keep_x_below = 0
+    slots.columns_from_chain = False
+    slots.products_per_half = False
+    slots.separate_halves = False
+    slots.aligned_flush = True
+    roles = [LeanRole("columns", joints=[j for j in range(n) if j % waves == w]) for w in range(waves)]
+    cost = {}
+    for c_ in range(n):
+        for h in (0, 1):
+            tr = core_gradient_recompute(spec, "id", use_qdd=use_qdd, cols=[(c_, h)], coop=(LeanRole("columns"), slots))
+            cost[(c_, h)] = lean_arith(tr, lean_barriers(tr)[-1]) + LEAN_FLUSH_SLOTS
+    plan = _lean_plan_runs(spec, slots, roles, cost, [0] * n, [0] * waves, 0, [1.0] * waves, [(0, 0)] * waves, 0)
+    return slots, plan
+
+
+def _lean_plan_runs(spec, slots, roles, cost, rec, slack, max_parked, speed, ph, t_b1, prefix_parking=False):
     """lean_plan(order="runs"): every wave takes ONE contiguous run of d/dq columns and ONE contiguous run of d/dqd columns.  The
     waves are taken in the order of their idle time before B1 (the busiest first); wave i gets the i-th run of the d/dq block
     counted from column 0 and the i-th run of the d/dqd block counted from column n-1 -- the heavy columns are the early ones in
@@ -428,10 +514,17 @@ def _lean_plan_runs(spec, slots, roles, cost, rec, slack, max_parked, speed, ph,
     def parked_of(s, a, b_):                                # d/dqd positions [a, b_) = columns n-b_ .. n-1-a
         if (s, a, b_) not in gains:
             g, chosen = 0, []
-            for c_ in sorted(range(n - b_, n - a), key=lambda c_: -rec[c_]):
-                if len(chosen) < max_parked and 0 < rec[c_] <= s - g:
+            if prefix_parking:      # (the first columns of the run, in the order they are processed: AlignedPieces wants neighbours)
+                for c_ in range(n - b_, n - a):
+                    if len(chosen) >= max_parked or not (0 < rec[c_] <= s - g):
+                        break
                     g += rec[c_]
                     chosen.append(c_)
+            else:
+                for c_ in sorted(range(n - b_, n - a), key=lambda c_: -rec[c_]):
+                    if len(chosen) < max_parked and 0 < rec[c_] <= s - g:
+                        g += rec[c_]
+                        chosen.append(c_)
             gains[(s, a, b_)] = (g, chosen)
         return gains[(s, a, b_)]
     INF = float("inf")
@@ -1192,8 +1285,9 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
         cols = sorted(want)
     tr.run_bases = []
     pass_halves = []        # (lean cores with separate_halves: the halves each pass of the column loop emits, in order)
+    stream = None           # (lean cores with aligned_flush: AlignedPieces, set once the order of the half-columns is known)
     if coop is not None:
-        assert kind == "fd" and not use_qdd_minv and not table and rollout is None
+        assert (kind == "fd" or lean) and not use_qdd_minv and not table and rollout is None
         role, slots = coop
         qdd = None          # (the prologue runs further down, once the per-column helpers it may call are defined)
     elif kind == "fd" and not use_qdd_minv:
@@ -1390,9 +1484,24 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
     lo_base = (lambda col: n * col) if cols is None else (lambda col: n * list(cols).index(col))
     hi_off = n * n if cols is None else n * len(cols)
 
+    def emit_run(col, h, values):
+        # lean cores: half-column runs in emission order -- through the sector-aligned stream (AlignedPieces), or as run k of the core
+        # (n values) that goes to row offset tr.run_bases[k] (grid_out_runs)
+        if stream is not None:
+            stream.push(n * col + h * n * n, list(values))
+            return
+        k_run = len(tr.run_bases)
+        tr.run_bases.append(n * col + h * n * n)
+        for r in range(n):
+            tr.out(n * k_run + r, values[r])
+
     def emit_column(col, dc):
         memo.clear()
         rows = sorted(dc)
+        if kind != "fd" and want is not None:           # lean inverse-dynamics-gradient core: the column itself is the output
+            for h in sorted(pass_halves.pop(0) if pass_halves else want[col]):
+                emit_run(col, h, [dc[r][h] if r in dc else tr.zero() for r in range(n)])
+            return
         if kind != "fd":
             for half in (0, 1):
                 for r in range(n):
@@ -1405,26 +1514,20 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
             halves = (pass_halves.pop(0) if pass_halves else want[col]) if want is not None else (0, 1)
             none = {k: tr.zero() for k in rows}
             if want is not None:
-                # half-column runs in emission order: run k of the core (n values) goes to row offset tr.run_bases[k] (grid_out_runs)
-                def emit_run(h, values):
-                    k_run = len(tr.run_bases)
-                    tr.run_bases.append(n * col + h * n * n)
-                    for r in range(n):
-                        tr.out(n * k_run + r, values[r])
                 if len(halves) == 2 and getattr(coop[1], "products_per_half", False):
                     # both halves of a column in one wave: ONE recursion, but the two products one after the other -- n accumulators
                     # alive instead of 2 n, for a second fetch of the Minv entries (2 multiply-adds per LDS read instead of 4)
                     lo, _ = alg.sym_minv_times_columns(tr, spec, lambda r, k: minv_entry(r, k), {k: dc[k][0] for k in rows}, none)
-                    emit_run(0, lo)
+                    emit_run(col, 0, lo)
                     _, hi = alg.sym_minv_times_columns(tr, spec, lambda r, k: minv_entry(r, k), none, {k: dqd_half[k] for k in rows})
-                    emit_run(1, hi)
+                    emit_run(col, 1, hi)
                     return
             lo, hi = alg.sym_minv_times_columns(tr, spec, lambda r, k: minv_entry(r, k),
                                                 {k: dc[k][0] for k in rows} if 0 in halves else none,
                                                 {k: dqd_half[k] for k in rows} if 1 in halves else none)
             if want is not None:
                 for h in sorted(halves):
-                    emit_run(h, (lo, hi)[h])
+                    emit_run(col, h, (lo, hi)[h])
                 return
             for r in range(n):
                 tr.out(lo_base(col) + r, lo[r])
@@ -1469,8 +1572,24 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
             alg.rnea_grad_columns(tr, spec, I, q, qd, trig, loader, capture, order=hoist, prefetch=0, xof=Xof, keep=keep,
                                   xof_back=Xof_back if lean else None, xa_first=lean)
         mark = tr.cse_mark()
-        u = [tr.inp("in.u(%d)" % j) for j in range(n)]
-        if lean:
+        u = [tr.inp("in.u(%d)" % j) for j in range(n)] if kind == "fd" else None
+        if lean and kind == "id":
+            # register-lean inverse-dynamics-gradient core: only the block's input table (sin, cos, qd and, with use_qdd, the given
+            # qdd in the qdd slots) and ONE barrier in front of the gradient half-columns
+            assert not tr.mixed, "the register-lean cores exist in the fp32 arithmetic only"
+            qdd_in = [tr.inp("in.qdd(%d)" % j) for j in range(n)] if use_qdd else None
+            for j in role.joints:
+                if trig[j] is not None:
+                    tr.xch_put(itab["s"][j], trig[j][0])
+                    tr.xch_put(itab["c"][j], trig[j][1])
+                else:
+                    tr.xch_put(itab["q"][j], q[j])
+                tr.xch_put(itab["qd"][j], qd[j])
+                if use_qdd:
+                    tr.xch_put(slots.qdd[j], qdd_in[j])
+            tr.barrier()
+            qdd = [tr.zero()] * n if use_qdd else None       # (placeholders: touch() reads the published qdd of every joint it visits)
+        elif lean:
             assert not tr.mixed, "the register-lean cores exist in the fp32 arithmetic only"
             # ---- phase 0: this wave's share of the block's input table, then B0 (everything below reads inputs through touch())
             for j in role.joints:
@@ -1480,7 +1599,8 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
                 else:
                     tr.xch_put(itab["q"][j], q[j])
                 tr.xch_put(itab["qd"][j], qd[j])
-                tr.xch_put(itab["u"][j], u[j])
+                if "u" in itab:
+                    tr.xch_put(itab["u"][j], u[j])
             tr.barrier()
             # ---- phase 1: backward pass of the Minv recursion (once per tree) | bias torques | parked d/dqd recursions, then B1
             def scratch(j, i):          # U_j (6) and 1/D_j of the backward pass: LDS words BELOW the exchange region -- the waves'
@@ -1494,7 +1614,8 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
                 memo.clear()
             if role.c_roots:
                 def publish_c(j, f):
-                    tr.xch_put(slots.c[j], f[spec.S_ind[j]] + qd[j] * spec.damping[j])
+                    c_j = f[spec.S_ind[j]] + qd[j] * spec.damping[j]
+                    tr.xch_put(slots.c[j], (u[j] - c_j) if slots.lean_umc else c_j)
                 ftab["hook"] = publish_c
                 for root in role.c_roots:
                     facc(root)
@@ -1524,7 +1645,7 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
                         if m is None:
                             continue
                         if k not in umc:
-                            umc[k] = tr.xch_get(itab["u"][k]) - tr.xch_get(slots.c[k])
+                            umc[k] = tr.xch_get(slots.c[k]) if slots.lean_umc else tr.xch_get(itab["u"][k]) - tr.xch_get(slots.c[k])
                         terms.append((m, umc[k]))
                     tr.xch_put(slots.qdd[r], tr.dot(terms))
             tr.barrier()
@@ -1550,6 +1671,20 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
                     passes.append((c_, tuple(sorted(want[c_]))))
             order = [c_ for (c_, _) in passes]
             pass_halves.extend(h_ for (_, h_) in passes)
+        if lean and getattr(slots, "aligned_flush", False) and want is not None:
+            # one pass per half-column, the d/dqd columns in ascending order (the parked ones first: lean_plan(order="runs") parks the
+            # first columns of the run), then the d/dq columns in ascending order: neighbours of the output row follow each other
+            hi_cols = sorted(c_ for c_ in want if 1 in want[c_])
+            hi_cols = [c_ for c_ in hi_cols if c_ in hoist] + [c_ for c_ in hi_cols if c_ not in hoist]
+            passes = [(c_, (1,)) for c_ in hi_cols] + [(c_, (0,)) for c_ in sorted(c_ for c_ in want if 0 in want[c_])]
+            order = [c_ for (c_, _) in passes]
+            del pass_halves[:]
+            pass_halves.extend(h_ for (_, h_) in passes)
+            seq = []                        # row offsets of the half-columns in the order they will be emitted
+            halves_of = list(pass_halves) if pass_halves else [tuple(sorted(want[c_])) for c_ in order]
+            for c_, hs in zip(order, halves_of):
+                seq += [n * c_ + h_ * n * n for h_ in hs]
+            stream = AlignedPieces(tr, n, 2 * n * n, seq)
         ftab["on"] = bool(slots.f_table)
     alg.rnea_grad_columns(tr, spec, I, q, qd, trig, loader, emit_column, order=order, prefetch=0, xof=Xof, keep=keep,
                           xof_back=Xof_back if lean else None, xa_first=lean)

@@ -116,7 +116,11 @@ int grid_get_split(grid_handle *h, int alg, int num_timesteps);
  * SIMD at <= 256 registers each -- a block-shared input table, the Minv recursion by base-rooted tree with its carried values parked in
  * LDS, gradient HALF columns as work items -- so that a second wave fills the issue slots and waits a lone 464-register wave leaves
  * empty.  grid_lean_available: 1 if emitted; grid_set_coop mode 3 = always this variant; automatic from FD_DU_LEAN_AUTO_MIN_TILES of
- * the generated header (0: on request only). */
+ * the generated header (0: on request only).  Its output leaves in contiguous runs per wave, cut at the 32-byte sectors of the row.
+ * The same block serves the INVERSE-dynamics gradient at qdd = 0 (`inverse_dynamics_gradient_kernel_coop8`, alg = GRID_ALG_ID_DU:
+ * input table, one barrier, gradient half-columns; replaces algorithms/_inverse_dynamics_gradient.py:199-246,501-540's
+ * block-per-configuration mapping for large robots): grid_lean_available(GRID_ALG_ID_DU), grid_set_coop(h, GRID_ALG_ID_DU, 0|1|3),
+ * automatic from ID_DU_LEAN_AUTO_MIN_TILES on; a call with d_qdd != NULL keeps the lane-per-configuration kernel. */
 int grid_coop_available(int alg);
 int grid_lean_available(int alg);
 int grid_set_coop(grid_handle *h, int alg, int mode);

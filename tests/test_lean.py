@@ -13,19 +13,21 @@ from gridcodegenerator_amd.emit import cores
 from gridcodegenerator_amd.emit.model import RobotSpec
 
 
-def emulate_lean_block(spec, slots, plan, q, qd, u):
+def emulate_lean_block(spec, slots, plan, q, qd, u, kind="fd", qdd=None):
     """The block's barriers separate its phases; phase p of every wave reads only what phases < p published.  Sweep p evaluates every
     wave's core against the exchange region as it stands and publishes the `xch` writes of PHASE p only (a Minv slot is written
     twice -- the backward pass's value before B1, the final value between B1 and B2 -- and the forward pass must read the former);
     the outputs are taken from the last sweep."""
     n, K = spec.n, q.shape[0]
-    traces = [cores.core_gradient_recompute(spec, "fd", cols=items, coop=(role, slots)) for (role, items) in plan]
+    traces = [cores.core_gradient_recompute(spec, kind, use_qdd=qdd is not None, cols=items, coop=(role, slots)) for (role, items) in plan]
     base = {"gravity": np.full(K, 9.81)}
     for j in range(n):
         base["in.q(%d)" % j] = q[:, j]; base["in.qd(%d)" % j] = qd[:, j]; base["in.u(%d)" % j] = u[:, j]
-    xch = {"in.xch_get(%d)" % s: np.zeros(K) for s in range(-7 * n, slots.count)}      # (negative: the parking words below the region)
+        if qdd is not None:
+            base["in.qdd(%d)" % j] = qdd[:, j]
+    xch = {"in.xch_get(%d)" % s: np.zeros(K) for s in range(-8 * n, slots.count)}      # (negative: the parking words below the region)
     got = np.full((K, 2 * n * n), np.nan)
-    phases = cores.LEAN_BARRIERS + 1
+    phases = (cores.LEAN_BARRIERS if kind == "fd" else 1) + 1
     with np.errstate(all="ignore"):
         for sweep in range(phases):
             new = {}
@@ -33,28 +35,44 @@ def emulate_lean_block(spec, slots, plan, q, qd, u):
                 inp = dict(base); inp.update(xch)
                 outs = tr.evaluate(inp)
                 phase = 0
+                piece = {}
                 for (dst, _), o in zip(tr.outputs, outs):
                     if dst == "barrier":
                         phase += 1
                     elif isinstance(dst, str) and dst.startswith("xch:"):
                         if phase == sweep:
                             new["in.xch_get(%s)" % dst[4:]] = np.broadcast_to(o, (K,)).astype(np.float32).astype(np.float64)
+                    elif isinstance(dst, str) and dst.startswith("piece:"):          # (AlignedPieces: values of a piece, then its flush)
+                        piece[int(dst.split(":")[2])] = o
+                    elif isinstance(dst, str) and dst.startswith("flush:"):
+                        _, length, offset = dst.split(":")
+                        assert sorted(piece) == list(range(int(length)))
+                        if sweep == phases - 1:
+                            for pos, val in piece.items():
+                                assert np.isnan(got[:, int(offset) + pos]).all(), "an output written twice"
+                                got[:, int(offset) + pos] = val
+                        piece = {}
                     elif not isinstance(dst, str) and sweep == phases - 1:
                         run, r = divmod(int(dst), n)
                         got[:, tr.run_bases[run] + r] = o
+                assert not piece
             xch.update(new)
     return got, traces
 
 
-@pytest.mark.parametrize("robot", ["atlas30", "mixed5", "iiwa7"])
-def test_lean_block_matches_oracle(robot, robots, tables):
+SCATTERED = dict(order="lpt", umc=False, aligned_flush=False)       # the first form of the planner / the sink (kept as options)
+
+
+@pytest.mark.parametrize("robot,options", [("atlas30", {}), ("atlas30", SCATTERED), ("mixed5", {}), ("iiwa7", {})],
+                         ids=["atlas30", "atlas30-scattered", "mixed5", "iiwa7"])
+def test_lean_block_matches_oracle(robot, options, robots, tables):
     from oracle import rbd_oracle as O
     spec = RobotSpec(robots(robot))
     n, K = spec.n, 3
     q, qd, u = (a.astype(np.float64) for a in make_inputs(n, K, 61))
     ref = O.fd_grad(tables(robot), q, qd, u)
     ref = np.concatenate([O.flat_colmajor(ref[:, :, :n]), O.flat_colmajor(ref[:, :, n:])], axis=1)
-    slots, plan = cores.lean_plan(spec)
+    slots, plan = cores.lean_plan(spec, **options)
     got, traces = emulate_lean_block(spec, slots, plan, q, qd, u)
     assert not np.isnan(got).any()                                      # every one of the 2 n^2 outputs is written by some wave
     assert relerr(got, ref)[0] < 5e-6                                   # (Minv, c, qdd cross the exchange region as fp32)
@@ -76,7 +94,7 @@ def test_lean_block_matches_oracle(robot, robots, tables):
     #  divide the largest tree's backward pass both run the chain and write the same values)
     assert all(len(ws) == 1 for (s_, ph_), ws in writers.items() if s_ >= 0), "a slot with two publishers in one phase"
     writers = {s_: ws for (s_, ph_), ws in writers.items()}
-    table = set(slots.itab["qd"]) | set(slots.itab["u"])
+    table = set(slots.itab["qd"]) | set(slots.itab.get("u", []))
     for j in range(n):
         table |= {slots.itab["s"][j], slots.itab["c"][j]} if spec.uses_trig[j] else {slots.itab["q"][j]}
     assert table <= set(writers) and set(slots.c) <= set(writers) and set(slots.qdd) <= set(writers) and set(slots.minv.values()) <= set(writers)
@@ -91,7 +109,7 @@ def test_lean_block_with_per_column_minv_matches_oracle(robots, tables):
     q, qd, u = (a.astype(np.float64) for a in make_inputs(n, K, 62))
     ref = O.fd_grad(tables("atlas30"), q, qd, u)
     ref = np.concatenate([O.flat_colmajor(ref[:, :, :n]), O.flat_colmajor(ref[:, :, n:])], axis=1)
-    slots, plan = cores.lean_plan(spec, columns_from_chain=True)
+    slots, plan = cores.lean_plan(spec, columns_from_chain=True, order="lpt", umc=False, aligned_flush=False)
     got, traces = emulate_lean_block(spec, slots, plan, q, qd, u)
     assert not np.isnan(got).any() and relerr(got, ref)[0] < 5e-6
     assert sorted(k for (role, _) in plan for k in role.minv_cols) == list(range(n))
@@ -108,7 +126,7 @@ def test_lean_block_in_contiguous_runs_matches_oracle(robot, robots, tables):
     q, qd, u = (a.astype(np.float64) for a in make_inputs(n, K, 63))
     ref = O.fd_grad(tables(robot), q, qd, u)
     ref = np.concatenate([O.flat_colmajor(ref[:, :, :n]), O.flat_colmajor(ref[:, :, n:])], axis=1)
-    slots, plan = cores.lean_plan(spec, order="runs")
+    slots, plan = cores.lean_plan(spec, order="runs", umc=False, aligned_flush=False)
     got, traces = emulate_lean_block(spec, slots, plan, q, qd, u)
     assert not np.isnan(got).any() and relerr(got, ref)[0] < 5e-6
     seen = []
@@ -119,7 +137,57 @@ def test_lean_block_in_contiguous_runs_matches_oracle(robot, robots, tables):
             seen += [(c, h) for c in cols]
         assert set(role.hoist) <= set(c for (c, h_) in items if h_ == 1)
     assert sorted(seen) == [(c, h) for c in range(n) for h in (0, 1)]
-    assert max(slots.lean_model["post"]) <= 1.05 * max(cores.lean_plan(spec)[0].lean_model["post"])     # balanced nearly as well as the scattered sets
+    lpt = cores.lean_plan(spec, order="lpt", umc=False, aligned_flush=False)[0]
+    assert max(slots.lean_model["post"]) <= 1.05 * max(lpt.lean_model["post"])       # balanced nearly as well as the scattered sets
+
+
+def test_lean_block_with_sector_aligned_pieces(robots, tables):
+    """lean_plan(order="runs", aligned_flush=True, umc=True): the output leaves in pieces cut at the 32-byte sectors of the row (at
+    most 32 values, the remainder carried into the next half-column's piece); u - c instead of c and u in LDS."""
+    from oracle import rbd_oracle as O
+    spec = RobotSpec(robots("atlas30"))
+    n, K = spec.n, 2
+    q, qd, u = (a.astype(np.float64) for a in make_inputs(n, K, 64))
+    ref = O.fd_grad(tables("atlas30"), q, qd, u)
+    ref = np.concatenate([O.flat_colmajor(ref[:, :, :n]), O.flat_colmajor(ref[:, :, n:])], axis=1)
+    slots, plan = cores.lean_plan(spec, order="runs", aligned_flush=True, umc=True)
+    assert "u" not in slots.itab and min(slots.c) == -8 * n
+    got, traces = emulate_lean_block(spec, slots, plan, q, qd, u)
+    assert not np.isnan(got).any() and relerr(got, ref)[0] < 5e-6
+    partial = total = 0
+    for tr in traces:
+        for (d, _) in tr.outputs:
+            if isinstance(d, str) and d.startswith("flush:"):
+                _, length, base = (int(x) if x.isdigit() else x for x in d.split(":"))
+                assert 1 <= length <= 32
+                total += 1
+                partial += (base % 8 != 0) + ((base + length) % 8 != 0)
+    # a half-column flushed as it is writes into two partial sectors (2 x 60 here); cut at the sectors only the ends of the 16 runs do
+    assert total <= 2 * n + 16 and partial <= 2 * 16, (total, partial)
+    for (role, items) in plan:              # the parked columns are the first d/dqd columns of the wave's run
+        hi = sorted(c for (c, h) in items if h == 1)
+        assert role.hoist == hi[:len(role.hoist)]
+
+
+@pytest.mark.parametrize("use_qdd", [False, True])
+def test_lean_inverse_dynamics_gradient_block_matches_oracle(use_qdd, robots, tables):
+    """The register-lean block of the INVERSE-dynamics gradient (cores.lean_plan_id: input table, one barrier, contiguous runs of
+    gradient half-columns, sector-aligned pieces) against the oracle's rnea_grad, with and without a given qdd."""
+    from oracle import rbd_oracle as O
+    spec = RobotSpec(robots("atlas30"))
+    n, K = spec.n, 2
+    q, qd, u = (a.astype(np.float64) for a in make_inputs(n, K, 65))
+    qdd = np.random.default_rng(66).uniform(-1.0, 1.0, (K, n)) if use_qdd else None
+    dc = O.rnea_grad(tables("atlas30"), q, qd, qdd if use_qdd else np.zeros((K, n)))
+    ref = np.concatenate([O.flat_colmajor(dc[:, :, :n]), O.flat_colmajor(dc[:, :, n:])], axis=1)
+    slots, plan = cores.lean_plan_id(spec, use_qdd)
+    got, traces = emulate_lean_block(spec, slots, plan, q, qd, u, kind="id", qdd=qdd)
+    assert not np.isnan(got).any() and relerr(got, ref)[0] < 2e-6           # (sin, cos, qd cross the input table as fp32)
+    assert sorted(it for (_, its) in plan for it in its) == [(c, h) for c in range(n) for h in (0, 1)]
+    for tr in traces:
+        assert [d for (d, _) in tr.outputs].count("barrier") == 1
+        assert tr.max_live()[0] <= 128
+    assert 4 * 64 * (slots.count + cores.LEAN_WAVES * 34) <= 160 * 1024     # (100 KB: one block of 8 x 256 registers fills a CU anyway)
 
 
 def test_lean_cores_stay_within_half_a_simd(robots):
@@ -133,8 +201,8 @@ def test_lean_cores_stay_within_half_a_simd(robots):
     assert worst <= 160, worst
     old = cores.CoopSlots(spec); old.ksplit = 15
     assert max_live(cores.core_gradient_recompute(spec, "fd", cols=[29], coop=("producer2", old))) > 256
-    assert 4 * 64 * (slots.count + cores.LEAN_WAVES * spec.n) <= 160 * 1024
-    assert 7 * spec.n <= cores.LEAN_WAVES * spec.n                      # U / 1/D parking fits the staging regions below the exchange region
+    assert 4 * 64 * (slots.count + cores.LEAN_WAVES * 34) <= 160 * 1024      # (staging rows of 34 words: pieces of 32 values)
+    assert 8 * spec.n <= cores.LEAN_WAVES * 34                          # U, 1/D and u - c fit the staging regions below the exchange region
 
 
 @pytest.mark.gpu
@@ -151,7 +219,7 @@ def test_lean_kernel_on_gpu(tables):
     with host.GridHandle(robot, device=0, precision=host.DEFAULT_PRECISION) as h:
         assert h.lean_available(host.ALG_FD_DU)
         attrs = h.L.kernel_attributes(host.ALG_FD_DU, coop=2)
-        assert attrs["numRegs"] <= 256 and attrs["maxThreadsPerBlock"] >= 512, attrs
+        assert attrs["numRegs"] <= 256 and attrs["maxThreadsPerBlock"] >= 512 and attrs["scratch_bytes_per_lane"] == 0, attrs
         n = h.n
         for K in (1, 70, 333, 1500):
             q, qd, u = make_inputs(n, K, 90 + K)
@@ -206,3 +274,96 @@ def test_lean_kernel_full_size_atlas30_16384(tables):
         h.forward_dynamics_gradient_device(d_out_p.data_ptr(), d_in_p.data_ptr(), 3 * n, K)
         h.synchronize()
         assert np.array_equal(d_out_p.cpu().numpy(), df[perm])
+
+
+@pytest.mark.gpu
+def test_lean_inverse_dynamics_gradient_kernel_on_gpu(tables):
+    """`inverse_dynamics_gradient_kernel_coop8` through the C ABI: automatic for Atlas-30 at qdd = 0 (grid_get_coop = 2), against the
+    oracle and against the lane-per-configuration kernel (other instruction order: to the parity tolerance); ragged batches, few blocks (grid-stride over tiles), rows past the batch untouched, a strided input
+    (2n values used of rows of 3n), 0 B of scratch at <= 256 registers; a call with a given qdd keeps the other kernel."""
+    import torch
+    from gridcodegenerator_amd import host
+    from test_gpu_parity import TOL, oracle_all, pack
+    robot, alg = "atlas30", host.ALG_ID_DU
+    host.build_library(robot, host.DEFAULT_PRECISION)
+    T = tables(robot)
+    with host.GridHandle(robot, device=0, precision=host.DEFAULT_PRECISION) as h:
+        assert h.lean_available(alg)
+        attrs = h.L.kernel_attributes(alg, coop=2)
+        assert attrs["numRegs"] <= 256 and attrs["maxThreadsPerBlock"] >= 512 and attrs["scratch_bytes_per_lane"] == 0, attrs
+        n = h.n
+        for K in (1, 70, 333, 1500):
+            q, qd, u = make_inputs(n, K, 190 + K)
+            ref = oracle_all(T, q, qd, u)["dc_du_noqdd"]
+            d_in = torch.from_numpy(pack(q, qd, u)).cuda()
+            h.set_coop(alg, 1); h.set_wave(alg, 1)
+            lanes = torch.zeros((K, 2 * n * n), dtype=torch.float32, device="cuda")
+            h.inverse_dynamics_gradient_device(lanes.data_ptr(), d_in.data_ptr(), 3 * n, K)
+            h.synchronize()
+            assert h.get_coop(alg, K) == 0
+            h.set_coop(alg, 0)
+            assert h.get_coop(alg, K) == 2                  # automatic (the wave-per-configuration kernel is switched off above)
+            outs = []
+            for blocks in (0, 1, 2):
+                out = torch.full((K + 2, 2 * n * n), 4.25, dtype=torch.float32, device="cuda")
+                h.inverse_dynamics_gradient_device(out.data_ptr(), d_in.data_ptr(), 3 * n, K, blocks=blocks)
+                h.synchronize()
+                o = out.cpu().numpy()
+                assert np.all(o[K:] == 4.25)
+                outs.append(o[:K])
+            assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+            err = relerr(outs[0], ref)[0]
+            print("lean dID kernel K=%d: dc_du error %.2e (lane-per-configuration kernel %.2e)" % (K, err, relerr(lanes.cpu().numpy(), ref)[0]))
+            assert err < TOL[robot]["dc_du"], (K, err)
+            assert relerr(outs[0], lanes.cpu().numpy().astype(np.float64))[0] < 2 * TOL[robot]["dc_du"]
+            zero = np.abs(ref).max(axis=0) == 0.0
+            assert np.all(outs[0][:, zero] == 0.0)
+            # compressed input rows (q, qd only: stride 2n) give the same bits
+            d_c = torch.from_numpy(np.ascontiguousarray(np.concatenate([q, qd], axis=1), dtype=np.float32)).cuda()
+            out = torch.zeros((K, 2 * n * n), dtype=torch.float32, device="cuda")
+            h.inverse_dynamics_gradient_device(out.data_ptr(), d_c.data_ptr(), 2 * n, K)
+            h.synchronize()
+            assert np.array_equal(out.cpu().numpy(), outs[0])
+        # a given qdd: not this kernel
+        K = 200
+        q, qd, u = make_inputs(n, K, 77)
+        d_in = torch.from_numpy(pack(q, qd, u)).cuda()
+        qdd = np.random.default_rng(78).uniform(-1, 1, (K, n)).astype(np.float32)
+        d_qdd = torch.from_numpy(qdd).cuda()
+        out = torch.zeros((K, 2 * n * n), dtype=torch.float32, device="cuda")
+        h.inverse_dynamics_gradient_device(out.data_ptr(), d_in.data_ptr(), 3 * n, K, d_qdd=d_qdd.data_ptr())
+        h.synchronize()
+        from oracle import rbd_oracle as O
+        dc = O.rnea_grad(T, q.astype(np.float64), qd.astype(np.float64), qdd.astype(np.float64))
+        ref = np.concatenate([O.flat_colmajor(dc[:, :, :n]), O.flat_colmajor(dc[:, :, n:])], axis=1)
+        assert relerr(out.cpu().numpy(), ref)[0] < TOL[robot]["dc_du"]
+        h.set_wave(alg, 0)
+
+
+@pytest.mark.gpu
+def test_lean_inverse_dynamics_gradient_full_size_atlas30_65536(tables):
+    """BASELINE config 4 (Atlas-30, batch 65536), the inverse-dynamics gradient through the automatic choice: spread sample against the
+    oracle, every row finite, permutation of the batch permutes the rows bit for bit."""
+    import torch
+    from gridcodegenerator_amd import host
+    from test_gpu_parity import TOL, oracle_all, pack
+    with host.GridHandle("atlas30", device=0, precision=host.DEFAULT_PRECISION) as h:
+        n, K, alg = h.n, 65536, host.ALG_ID_DU
+        assert h.get_coop(alg, K) == 2
+        q, qd, u = make_inputs(n, K, 5)
+        x = pack(q, qd, u)
+        d_in = torch.from_numpy(x).cuda()
+        d_out = torch.empty((K, 2 * n * n), dtype=torch.float32, device="cuda")
+        h.inverse_dynamics_gradient_device(d_out.data_ptr(), d_in.data_ptr(), 3 * n, K)
+        h.synchronize()
+        assert bool(torch.isfinite(d_out).all().item())
+        rows = np.unique(np.concatenate([np.arange(64), np.linspace(0, K - 1, 96).astype(int), np.arange(K - 64, K)]))
+        ref = oracle_all(tables("atlas30"), q[rows], qd[rows], u[rows])["dc_du_noqdd"]
+        dc_rows = d_out[torch.from_numpy(rows).cuda()].cpu().numpy()
+        assert relerr(dc_rows, ref)[0] < TOL["atlas30"]["dc_du"]
+        perm = torch.from_numpy(np.random.default_rng(6).permutation(K)).cuda()
+        d_out_p = torch.empty_like(d_out)
+        d_in_p = d_in[perm].contiguous()
+        h.inverse_dynamics_gradient_device(d_out_p.data_ptr(), d_in_p.data_ptr(), 3 * n, K)
+        h.synchronize()
+        assert bool(torch.equal(d_out_p, d_out[perm]))

@@ -25,5 +25,18 @@ for name in todo:
         h.time_device(alg, d_out.data_ptr(), d_in.data_ptr(), 3 * n, K, reps=reps)
         us = min(h.time_device(alg, d_out.data_ptr(), d_in.data_ptr(), 3 * n, K, reps=reps) for _ in range(3)) * 1e3
         row.append("K=%d %7.2f us" % (K, us))
-    print("%-24s regs %3d scratch %4d B | %s" % (name, a["numRegs"], a["scratch_bytes_per_lane"], " | ".join(row)), flush=True)
+    # outputs against the shipped library's (ragged batch, rows past the batch untouched)
+    Kp = 1500 + 37
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(-np.pi, np.pi, (Kp, n)), rng.uniform(-1, 1, (Kp, 2 * n))], axis=1).astype(np.float32)
+    d_in = torch.from_numpy(x).cuda(); d_out = torch.full((Kp + 3, 2 * n * n), -7.0, dtype=torch.float32, device='cuda')
+    h.forward_dynamics_gradient_device(d_out.data_ptr(), d_in.data_ptr(), 3 * n, Kp); h.synchronize()
+    res = d_out.cpu().numpy()
+    if name == "atlas30":
+        ref_out = res
+        check = "reference"
+    else:
+        err = np.abs(res[:Kp] - ref_out[:Kp]).max() / np.abs(ref_out[:Kp]).max()
+        check = "max|diff|/max|ref| %.1e, untouched rows %s" % (err, bool((res[Kp:] == -7.0).all()))
+    print("%-24s regs %3d scratch %4d B | %s | %s" % (name, a["numRegs"], a["scratch_bytes_per_lane"], " | ".join(row), check), flush=True)
     h.close()
