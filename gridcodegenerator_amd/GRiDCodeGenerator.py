@@ -76,9 +76,8 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, SpatialAlgebraEmitMixin, Al
                                 # 1.4-2.5 against 8.83-8.96 for the flush-balanced 4-way split: rejected (same file)
         wave_occupancy=1,       # wave-per-configuration kernels: waves per SIMD the register allocation must leave room for (2: <= 256 registers)
         lean_read_ahead=0,      # register-lean 8-wave kernel: LDS reads issued this many instructions ahead of their use (Tracer.emit read_ahead)
-        lean_row_loads=True,    # register-lean 8-wave kernel: every lane reads the inputs its wave needs straight from its configuration's row
-                                # instead of all 3n inputs staged through LDS by each of the 8 waves (False: Atlas-30 K = 16384 53.3 -> 48.5 us
-                                # together with u - c published instead of c and u: profiles/r04/lean_store_path.txt)
+        lean_min_joints=13,     # register-lean 8-wave kernels for robots with at least this many joints
+        lean_id_plan={},        # register-lean inverse-dynamics-gradient kernel: keyword overrides of cores.lean_plan_id (chain_f)
         lean_plan={},           # register-lean 8-wave kernel: keyword overrides of cores.lean_plan (younger_speed, max_parked)
         lean_probe=None,        # register-lean 8-wave kernel, timing probes (NOT a correct kernel): "prefix" = phases 0-2 only, "older" / "younger" =
                                 # only the waves dispatched first / last keep their gradient half-columns (profiles/r04/lean_probes.txt)
@@ -158,8 +157,9 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, SpatialAlgebraEmitMixin, Al
         self.split_flush_slots = exp["split_flush_slots"] if exp["split_flush_slots"] == "flush" else float(exp["split_flush_slots"])
         self.split_asym = float(exp["split_asym"])
         self.lean_plan_options = dict(exp["lean_plan"])
+        self.lean_id_plan_options = dict(exp["lean_id_plan"])
         self.lean_read_ahead = int(exp["lean_read_ahead"])
-        self.lean_row_loads = bool(exp["lean_row_loads"])
+        self.lean_min_joints = int(exp["lean_min_joints"])
         self.in_rows = bool(exp["in_rows"])
         self.split_half_columns = bool(exp["split_half_columns"])
         self.lean_id_auto_min_tiles = 1    # register-lean inverse-dynamics-gradient kernel: automatic from this many tiles on

@@ -1857,7 +1857,7 @@ class AlgorithmEmitMixin:
         n = self.spec.n
         W = cores.LEAN_WAVES
         self._lean_cache = None
-        if n <= 12 or self.precision != "fp32" or self.grad_schedule != "recompute":
+        if n < self.lean_min_joints or self.precision != "fp32" or (self.grad_schedule != "recompute" and n > 12):
             return None
         slots, plan = cores.lean_plan(self.spec, W, **self.lean_plan_options)
         if self.lean_probe == "prefix":             # (experiment: phases 0-3 only -- what a tile costs before its first gradient column)
@@ -1871,8 +1871,6 @@ class AlgorithmEmitMixin:
         # per wave: one gradient half-column per flush (or one piece of at most 32 values at a pitch of 34: AlignedPieces); before
         # the first flush the staging regions park U, 1/D of the Minv recursion (7 n words per lane) and u - c (n more, lean_umc)
         stage = WAVE * (34 if getattr(slots, "aligned_flush", False) else n)
-        if not self.lean_row_loads:
-            stage = max(stage, WAVE * n)             # (the staged input load goes through the same region, n values at a time)
         lds_elems = W * stage + WAVE * slots.count
         if 4 * lds_elems > 160 * 1024 or (8 if slots.lean_umc else 7) * n > W * (stage // WAVE):
             self.note("no register-lean 8-wave tile-cooperative kernel (FD_DU_LEAN_WAVES = 0): exchange region + input table + 8 staging "
@@ -1959,16 +1957,15 @@ class AlgorithmEmitMixin:
             "for (int k0 = bid*GRID_WAVE_SIZE; k0 < NUM_TIMESTEPS; k0 += nblocks*GRID_WAVE_SIZE){",
         ])
         self.indent_level += 1
-        if self.lean_row_loads:
-            # every lane reads the few inputs its wave needs (its share of the input table, u of the bias-torque joints) straight from
-            # its configuration's row: 8 waves staging all 3n inputs each was ~300 instructions per wave for ~12 values used
-            self.gen_add_code_line("const T *s_q_qd_u = d_q_qd_u + (size_t)min(k0 + it.lane, NUM_TIMESTEPS - 1)*stride_q_qd_u;")
-        else:
-            self.gen_add_code_line("T s_q_qd_u[%d];" % (3 * n))
-            self._emit_load("s_q_qd_u", "d_q_qd_u", 3 * n, "stride_q_qd_u", piece)
+        # every lane reads the few inputs its wave needs (its share of the input table, u of the bias-torque joints) straight from its
+        # configuration's row: 8 waves staging all 3n inputs each was ~300 instructions per wave for ~12 values used (Atlas-30 K = 16384
+        # 53.3 -> 48.5 us together with u - c published instead of c and u: profiles/r04/lean_store_path.txt).  Wave-uniform base of
+        # the tile + one 32-bit per-lane row offset; lanes past the batch read the last valid row
+        self.gen_add_code_line("const T *s_q_qd_u = grid_opaque_uniform(d_q_qd_u + (size_t)k0*stride_q_qd_u);")
+        self.gen_add_code_line("const unsigned in_row = (unsigned)min(it.lane, NUM_TIMESTEPS - 1 - k0)*(unsigned)stride_q_qd_u*(unsigned)sizeof(T);")
         self.gen_add_code_line("const unsigned xb = (unsigned)reinterpret_cast<unsigned long long>(s_xch) + (unsigned)sizeof(T)*it.lane;")
         self.gen_add_code_line("const grid_in_lean<T> in = {s_q_qd_u, s_q_qd_u + %d, s_q_qd_u + %d, s_xch, it.lane, xb, xb + 256u*GRID_WAVE_SIZE*(unsigned)sizeof(T), "
-                               "xb - 256u*GRID_WAVE_SIZE*(unsigned)sizeof(T)};" % (n, 2 * n))
+                               "xb - 256u*GRID_WAVE_SIZE*(unsigned)sizeof(T), in_row};" % (n, 2 * n))
         self.gen_add_code_line("switch (it.wave_in_block){", True)
         for w, (cname, bases, pieces) in enumerate(names):
             self.gen_add_code_line("case %d: {" % w, True)
@@ -2027,9 +2024,9 @@ class AlgorithmEmitMixin:
             return self._lean_id_cache
         n, W = self.spec.n, cores.LEAN_WAVES
         self._lean_id_cache = None
-        if n <= 12 or self.precision != "fp32" or self.grad_schedule != "recompute":
+        if n < self.lean_min_joints or self.precision != "fp32" or (self.grad_schedule != "recompute" and n > 12):
             return None
-        slots, plan = cores.lean_plan_id(self.spec, False, W)
+        slots, plan = cores.lean_plan_id(self.spec, False, W, **self.lean_id_plan_options)
         stage = WAVE * 34
         lds_elems = W * stage + WAVE * slots.count
         if 4 * lds_elems > 160 * 1024:
@@ -2115,10 +2112,12 @@ class AlgorithmEmitMixin:
             "for (int k0 = bid*GRID_WAVE_SIZE; k0 < NUM_TIMESTEPS; k0 += nblocks*GRID_WAVE_SIZE){",
         ])
         self.indent_level += 1
-        self.gen_add_code_line("const T *s_q_qd = d_q_qd + (size_t)min(k0 + it.lane, NUM_TIMESTEPS - 1)*stride_q_qd;     // every lane reads the few inputs its wave needs from its row")
+        self.gen_add_code_line("// every lane reads the few inputs its wave needs from its row: wave-uniform base of the tile + one 32-bit per-lane row offset")
+        self.gen_add_code_line("const T *s_q_qd = grid_opaque_uniform(d_q_qd + (size_t)k0*stride_q_qd);")
+        self.gen_add_code_line("const unsigned in_row = (unsigned)min(it.lane, NUM_TIMESTEPS - 1 - k0)*(unsigned)stride_q_qd*(unsigned)sizeof(T);")
         self.gen_add_code_line("const unsigned xb = (unsigned)reinterpret_cast<unsigned long long>(s_xch) + (unsigned)sizeof(T)*it.lane;")
         self.gen_add_code_line("const grid_in_lean<T> in = {s_q_qd, s_q_qd + %d, nullptr, s_xch, it.lane, xb, xb + 256u*GRID_WAVE_SIZE*(unsigned)sizeof(T), "
-                               "xb - 256u*GRID_WAVE_SIZE*(unsigned)sizeof(T)};" % n)
+                               "xb - 256u*GRID_WAVE_SIZE*(unsigned)sizeof(T), in_row};" % n)
         self.gen_add_code_line("switch (it.wave_in_block){", True)
         for w, cname in enumerate(names):
             self.gen_add_code_line("case %d: {" % w, True)

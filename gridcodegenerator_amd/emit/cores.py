@@ -244,8 +244,9 @@ class AlignedPieces:
     n values of a half-column are not flushed as they are -- 120 bytes at an 8-byte aligned offset: every flush leaves two partly
     written 32-byte sectors per configuration, which the memory side writes as whole sectors (WRITE_SIZE 1.23x the output, and the
     pure store stream of K = 65536 takes 187 us against 159 us in aligned pieces: profiles/r04/ubench_store_pieces.txt) -- but cut at
-    the sector boundaries of the row: the values past the last boundary stay in registers (at most 7) and leave with the next
-    half-column, which continues the same run.  A piece is at most 32 values; only the two ends of a run write partial sectors.
+    the sector boundaries of the row: the values past the last boundary (below the first one, when the run is walked downwards)
+    stay in registers (at most 7) and leave with the next half-column, which continues the same run.  A piece is at most 32
+    values; only the two ends of a run write partial sectors.
     The row itself starts on a sector boundary when 2 n^2 is a multiple of 8 (n even); otherwise no cutting.
 
     Emits, per piece: tr.out("piece:<len>:<pos>", value) for its values, then tr.out("flush:<len>:<row offset>", 0)."""
@@ -257,32 +258,51 @@ class AlignedPieces:
         self.tr, self.n, self.bases = tr, n, list(bases)
         self.unit = self.SECTOR if row % self.SECTOR == 0 else 1
         self.k = 0
-        self.start, self.vals = None, []
-        self.pieces = []            # (row offset, length) of every emitted piece, in order
+        self.lo, self.vals = None, []       # pending values: row offsets lo .. lo + len(vals)
+        self.pieces = []                    # (row offset, length) of every emitted piece, in order
+
+    def _emit(self, lo, hi):
+        """Write the pending values of row offsets [lo, hi) -- one end of the pending interval -- in pieces of at most MAX_PIECE values
+        whose inner boundaries are sector boundaries."""
+        first = lo - self.lo
+        vals = self.vals[first:first + hi - lo]
+        at = lo
+        while at < hi:
+            stop = min(hi, ((at + self.MAX_PIECE) // self.unit) * self.unit if hi - at > self.MAX_PIECE else hi)
+            length = stop - at
+            for pos in range(length):
+                self.tr.out("piece:%d:%d" % (length, pos), vals[at - lo + pos])
+            self.tr.out("flush:%d:%d" % (length, at), 0.0)
+            self.pieces.append((at, length))
+            at = stop
+        if lo == self.lo:
+            self.vals, self.lo = self.vals[hi - lo:], hi
+        else:
+            assert hi == self.lo + len(self.vals)
+            self.vals = self.vals[:first]
 
     def push(self, base, values):
         assert base == self.bases[self.k] and len(values) == self.n
         self.k += 1
-        if self.vals:
-            assert self.start + len(self.vals) == base
+        if not self.vals:
+            self.lo, self.vals = base, list(values)
+        elif self.lo + len(self.vals) == base:          # continues the run upwards
+            self.vals += list(values)
+        else:                                           # ... or downwards
+            assert base + self.n == self.lo
+            self.lo, self.vals = base, list(values) + self.vals
+        lo, hi = self.lo, self.lo + len(self.vals)
+        nxt = self.bases[self.k] if self.k < len(self.bases) else None
+        if nxt is not None and nxt == hi:               # the next half-column continues upwards: keep what lies past the last boundary
+            cut = (hi // self.unit) * self.unit
+            if cut > lo:
+                self._emit(lo, cut)
+        elif nxt is not None and nxt + self.n == lo:    # ... downwards: keep what lies below the first boundary
+            cut = -((-lo) // self.unit) * self.unit
+            if cut < hi:
+                self._emit(cut, hi)
         else:
-            self.start = base
-        self.vals += values
-        end = base + self.n
-        ascending = self.k < len(self.bases) and self.bases[self.k] == end
-        cut = (end // self.unit) * self.unit if ascending else end
-        if cut <= self.start:
-            return                  # (nothing complete yet: everything is carried)
-        while self.start < cut:
-            length = cut - self.start
-            if length > self.MAX_PIECE:     # (the end of a run: carried values + a whole half-column -- the aligned part, then the tail)
-                length = ((self.start + self.MAX_PIECE) // self.unit) * self.unit - self.start
-            for pos in range(length):
-                self.tr.out("piece:%d:%d" % (length, pos), self.vals[pos])
-            self.tr.out("flush:%d:%d" % (length, self.start), 0.0)
-            self.pieces.append((self.start, length))
-            self.vals = self.vals[length:]
-            self.start += length
+            self._emit(lo, hi)
 
 
 class LeanRole:
@@ -334,7 +354,7 @@ def lean_barriers(tr):
 
 
 def lean_plan(spec, waves=LEAN_WAVES, max_parked=3, younger_speed=None, keep_x_below=0, columns_from_chain=False, order="runs",
-              products_per_half=False, separate_halves=False, umc=True, aligned_flush=True):
+              products_per_half=False, separate_halves=False, umc=True, aligned_flush=True, chain_f=True):
     """Who does what in a register-lean block of `waves` wavefronts (two per SIMD): returns (slots, [(LeanRole, [(column, half)])]).
 
     Phase 0 (input table): joints dealt round-robin.  Phase 1: the BACKWARD pass of the Minv recursion once per base-rooted tree -- the
@@ -360,6 +380,7 @@ def lean_plan(spec, waves=LEAN_WAVES, max_parked=3, younger_speed=None, keep_x_b
     slots.products_per_half = bool(products_per_half)
     slots.separate_halves = bool(separate_halves)
     slots.aligned_flush = bool(aligned_flush)
+    slots.chain_f = bool(chain_f)
     trees = sorted(base_trees(spec), key=lambda t: -t[1])
     big = list(range(trees[0][0], trees[0][0] + trees[0][1]))
     rest = [j for (f, m) in trees[1:] for j in range(f, f + m)]
@@ -439,8 +460,9 @@ def lean_plan(spec, waves=LEAN_WAVES, max_parked=3, younger_speed=None, keep_x_b
         rec[c_] = lean_arith(trp, b[0], b[1])
     speed = [1.0 if w < waves // 2 else (LEAN_YOUNGER_SPEED if younger_speed is None else younger_speed) for w in range(waves)]
     if order == "runs":
+        top_extra = _chained_costs(spec, cost, lambda items: (lambda tr: lean_arith(tr, lean_barriers(tr)[-1]))(probe(LeanRole("consumer"), items))) if chain_f else None
         return slots, _lean_plan_runs(spec, slots, roles, cost, rec, [t_b1 - p1 for (p1, _) in ph], max_parked, speed, ph, t_b1,
-                                      prefix_parking=aligned_flush)
+                                      prefix_parking=aligned_flush, top_extra=top_extra)
     assert order == "lpt", order
     load = [0.0] * waves
     items = [[] for _ in range(waves)]
@@ -473,11 +495,29 @@ def lean_plan(spec, waves=LEAN_WAVES, max_parked=3, younger_speed=None, keep_x_b
     return slots, plan
 
 
-def lean_plan_id(spec, use_qdd=False, waves=LEAN_WAVES):
+def _chained_costs(spec, cost, post_arith):
+    """chain_f: replaces cost[(c, 0)] by what the d/dq half of column c costs right behind column c + 1 in the same wave (the
+    accumulated force of c + 1 is reused when c + 1 is a child of c) and returns top_extra[c] = what it costs more on its own."""
+    n = spec.n
+    top_extra = [0.0] * n
+    for c_ in range(n - 1):
+        if spec.parent[c_ + 1] == c_ and spec.parent[c_] != -1:
+            behind = post_arith([(c_ + 1, 0), (c_, 0)]) - post_arith([(c_ + 1, 0)]) + LEAN_FLUSH_SLOTS
+            top_extra[c_] = max(0.0, cost[(c_, 0)] - behind)
+            cost[(c_, 0)] = min(cost[(c_, 0)], behind)
+    return top_extra
+
+
+def lean_plan_id(spec, use_qdd=False, waves=LEAN_WAVES, chain_f=False):
     """Who does what in a register-lean block of the INVERSE-dynamics gradient (dc_du at (q, qd[, qdd]); 8 waves per tile, two per
     SIMD): every wave writes its share of the block's input table, one barrier, then its gradient half-columns -- one contiguous
     run of d/dq columns and one of d/dqd columns each, cut by the same dynamic programme as the forward-dynamics kernel's (no Minv,
-    no bias torques, nothing to park).  Returns (slots, [(LeanRole, [(column, half)])])."""
+    no bias torques, nothing to park).  Returns (slots, [(LeanRole, [(column, half)])]).
+
+    chain_f (the accumulated force of the column finished last reused by its parent's column, as in lean_plan) is OFF here: it
+    takes 12.7 % of the instructions away (54.6 k -> 47.7 k per Atlas-30 tile) and K = 64 from 23.0 to 20.4 us, but hipcc then needs
+    more than 256 registers for the wave that holds the two heaviest d/dqd columns (104 B of scratch; 122 registers and none
+    without) and the full chip gets slower: K = 16384 32.4 -> 33.4 us, K = 65536 206 -> 217 us (profiles/r04/lean_chain_f.txt)."""
     n = spec.n
     slots = CoopSlots(spec)
     slots.minv = {}                      # (no Minv in this kernel: the region holds the input table and, with use_qdd, qdd)
@@ -487,17 +527,19 @@ def lean_plan_id(spec, use_qdd=False, waves=LEAN_WAVES):
     slots.products_per_half = False
     slots.separate_halves = False
     slots.aligned_flush = True
+    slots.chain_f = bool(chain_f)
     roles = [LeanRole("columns", joints=[j for j in range(n) if j % waves == w]) for w in range(waves)]
-    cost = {}
-    for c_ in range(n):
-        for h in (0, 1):
-            tr = core_gradient_recompute(spec, "id", use_qdd=use_qdd, cols=[(c_, h)], coop=(LeanRole("columns"), slots))
-            cost[(c_, h)] = lean_arith(tr, lean_barriers(tr)[-1]) + LEAN_FLUSH_SLOTS
-    plan = _lean_plan_runs(spec, slots, roles, cost, [0] * n, [0] * waves, 0, [1.0] * waves, [(0, 0)] * waves, 0)
+
+    def post_arith(items):
+        tr = core_gradient_recompute(spec, "id", use_qdd=use_qdd, cols=items, coop=(LeanRole("columns"), slots))
+        return lean_arith(tr, lean_barriers(tr)[-1])
+    cost = {(c_, h): post_arith([(c_, h)]) + LEAN_FLUSH_SLOTS for c_ in range(n) for h in (0, 1)}
+    top_extra = _chained_costs(spec, cost, post_arith) if chain_f else None
+    plan = _lean_plan_runs(spec, slots, roles, cost, [0] * n, [0] * waves, 0, [1.0] * waves, [(0, 0)] * waves, 0, top_extra=top_extra)
     return slots, plan
 
 
-def _lean_plan_runs(spec, slots, roles, cost, rec, slack, max_parked, speed, ph, t_b1, prefix_parking=False):
+def _lean_plan_runs(spec, slots, roles, cost, rec, slack, max_parked, speed, ph, t_b1, prefix_parking=False, top_extra=None):
     """lean_plan(order="runs"): every wave takes ONE contiguous run of d/dq columns and ONE contiguous run of d/dqd columns.  The
     waves are taken in the order of their idle time before B1 (the busiest first); wave i gets the i-th run of the d/dq block
     counted from column 0 and the i-th run of the d/dqd block counted from column n-1 -- the heavy columns are the early ones in
@@ -509,6 +551,8 @@ def _lean_plan_runs(spec, slots, roles, cost, rec, slack, max_parked, speed, ph,
     for c_ in range(n):
         pq.append(pq[-1] + cost[(c_, 0)])
         pd.append(pd[-1] + cost[(n - 1 - c_, 1)])          # (position k of the d/dqd sequence is column n-1-k)
+    # chain_f: cost[(c, 0)] is what column c costs BEHIND column c + 1 in the same wave; the highest column of a run pays top_extra[c] more
+    top_of = (lambda a, e: top_extra[e - 1] if (top_extra is not None and e > a) else 0.0)
     gains = {}
 
     def parked_of(s, a, b_):                                # d/dqd positions [a, b_) = columns n-b_ .. n-1-a
@@ -538,7 +582,7 @@ def _lean_plan_runs(spec, slots, roles, cost, rec, slack, max_parked, speed, ph,
         last = i == waves
         for (aq, ad), (top, _) in layers[-1].items():
             for eq in ((n,) if last else range(aq, n + 1)):
-                lq = pq[eq] - pq[aq]
+                lq = pq[eq] - pq[aq] + top_of(aq, eq)
                 if lq / speed[w] >= (nxt.get((n, n), (INF,))[0] if last else INF):
                     break
                 for ed in ((n,) if last else range(ad, n + 1)):
@@ -562,7 +606,7 @@ def _lean_plan_runs(spec, slots, roles, cost, rec, slack, max_parked, speed, ph,
         aq, eq, ad, ed = plan_of[w]
         role.hoist = sorted(parked_of(slack[w], ad, ed)[1])
         plan.append((role, sorted([(c_, 0) for c_ in range(aq, eq)] + [(c_, 1) for c_ in range(n - ed, n - ad)])))
-        post.append((pq[eq] - pq[aq] + pd[ed] - pd[ad] - parked_of(slack[w], ad, ed)[0]) / speed[w])
+        post.append((pq[eq] - pq[aq] + top_of(aq, eq) + pd[ed] - pd[ad] - parked_of(slack[w], ad, ed)[0]) / speed[w])
     slots.lean_model = dict(phase1=[p1 for (p1, _) in ph], phase2=[p2 for (_, p2) in ph], t_b1=t_b1, post=post,
                             runs=[(plan_of[w][0], plan_of[w][1], n - plan_of[w][3], n - plan_of[w][2]) for w in range(waves)])
     return plan
@@ -1417,6 +1461,7 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
             memo[("a", j)] = a
         return memo[("a", j)]
 
+    chain = {"f": None, "for": None}       # lean cores: (joint, its accumulated force) of the d/dq column finished last | the joint being accumulated
     ftab = {"on": False, "done": set(), "hook": None}     # tile-cooperative cores: f of the wave's own finished columns lives in LDS (CoopSlots.f)
 
     def facc(j):
@@ -1427,7 +1472,9 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
             f = alg.vadd(alg.matvec(tr, I[j], a_of(j)), alg.fxv(tr, v, alg.matvec(tr, I[j], v)))
             for ch in spec.children[j]:
                 if lean:
-                    fch = facc(ch)
+                    # the accumulated force of the column this wave finished just before, when that is a child of this one (runs of
+                    # d/dq columns are walked towards the root): six registers instead of the child's whole subtree once more
+                    fch = chain["f"][1] if (chain["f"] is not None and chain["f"][0] == ch and j == chain["for"]) else facc(ch)
                     f = alg.mattvec_acc(tr, Xof_back(ch), fch, f)
                 else:
                     f = alg.mattvec_acc(tr, Xof(ch), facc(ch), f)
@@ -1455,10 +1502,13 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
             # the walk that accumulates the column joint's force visits the joint's whole subtree; what it computed on the way (v, a, X
             # of every joint below) is forgotten -- the gradient walk recomputes v where it needs it -- otherwise 6-12 values per subtree
             # joint stay alive from here to their visit (18 joints below the torso: 100+ registers)
+            chain["for"] = j if getattr(coop[1], "chain_f", False) else None
             f = facc(j)
+            chain["for"] = None
             below = set(spec.subtree[j]) - {j}
             for key in [key for key in memo if key[1] in below]:
                 del memo[key]
+            chain["f"] = (j, f)
             return f
         if kind_ == "f" and ftab["on"]:
             # The accumulated force of a column's joint walks the joint's whole subtree -- unless a child is a column this wave has
@@ -1676,7 +1726,8 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
             # first columns of the run), then the d/dq columns in ascending order: neighbours of the output row follow each other
             hi_cols = sorted(c_ for c_ in want if 1 in want[c_])
             hi_cols = [c_ for c_ in hi_cols if c_ in hoist] + [c_ for c_ in hi_cols if c_ not in hoist]
-            passes = [(c_, (1,)) for c_ in hi_cols] + [(c_, (0,)) for c_ in sorted(c_ for c_ in want if 0 in want[c_])]
+            passes = [(c_, (1,)) for c_ in hi_cols] + [(c_, (0,)) for c_ in sorted((c_ for c_ in want if 0 in want[c_]),
+                                                                                      reverse=getattr(slots, "chain_f", False))]
             order = [c_ for (c_, _) in passes]
             del pass_halves[:]
             pass_halves.extend(h_ for (_, h_) in passes)

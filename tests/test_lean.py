@@ -60,7 +60,7 @@ def emulate_lean_block(spec, slots, plan, q, qd, u, kind="fd", qdd=None):
     return got, traces
 
 
-SCATTERED = dict(order="lpt", umc=False, aligned_flush=False)       # the first form of the planner / the sink (kept as options)
+SCATTERED = dict(order="lpt", umc=False, aligned_flush=False, chain_f=False)       # the first form of the planner / the sink (kept as options)
 
 
 @pytest.mark.parametrize("robot,options", [("atlas30", {}), ("atlas30", SCATTERED), ("mixed5", {}), ("iiwa7", {})],
@@ -109,7 +109,7 @@ def test_lean_block_with_per_column_minv_matches_oracle(robots, tables):
     q, qd, u = (a.astype(np.float64) for a in make_inputs(n, K, 62))
     ref = O.fd_grad(tables("atlas30"), q, qd, u)
     ref = np.concatenate([O.flat_colmajor(ref[:, :, :n]), O.flat_colmajor(ref[:, :, n:])], axis=1)
-    slots, plan = cores.lean_plan(spec, columns_from_chain=True, order="lpt", umc=False, aligned_flush=False)
+    slots, plan = cores.lean_plan(spec, columns_from_chain=True, **SCATTERED)
     got, traces = emulate_lean_block(spec, slots, plan, q, qd, u)
     assert not np.isnan(got).any() and relerr(got, ref)[0] < 5e-6
     assert sorted(k for (role, _) in plan for k in role.minv_cols) == list(range(n))
@@ -126,7 +126,7 @@ def test_lean_block_in_contiguous_runs_matches_oracle(robot, robots, tables):
     q, qd, u = (a.astype(np.float64) for a in make_inputs(n, K, 63))
     ref = O.fd_grad(tables(robot), q, qd, u)
     ref = np.concatenate([O.flat_colmajor(ref[:, :, :n]), O.flat_colmajor(ref[:, :, n:])], axis=1)
-    slots, plan = cores.lean_plan(spec, order="runs", umc=False, aligned_flush=False)
+    slots, plan = cores.lean_plan(spec, order="runs", umc=False, aligned_flush=False, chain_f=False)
     got, traces = emulate_lean_block(spec, slots, plan, q, qd, u)
     assert not np.isnan(got).any() and relerr(got, ref)[0] < 5e-6
     seen = []
@@ -137,7 +137,7 @@ def test_lean_block_in_contiguous_runs_matches_oracle(robot, robots, tables):
             seen += [(c, h) for c in cols]
         assert set(role.hoist) <= set(c for (c, h_) in items if h_ == 1)
     assert sorted(seen) == [(c, h) for c in range(n) for h in (0, 1)]
-    lpt = cores.lean_plan(spec, order="lpt", umc=False, aligned_flush=False)[0]
+    lpt = cores.lean_plan(spec, **SCATTERED)[0]
     assert max(slots.lean_model["post"]) <= 1.05 * max(lpt.lean_model["post"])       # balanced nearly as well as the scattered sets
 
 
@@ -150,7 +150,7 @@ def test_lean_block_with_sector_aligned_pieces(robots, tables):
     q, qd, u = (a.astype(np.float64) for a in make_inputs(n, K, 64))
     ref = O.fd_grad(tables("atlas30"), q, qd, u)
     ref = np.concatenate([O.flat_colmajor(ref[:, :, :n]), O.flat_colmajor(ref[:, :, n:])], axis=1)
-    slots, plan = cores.lean_plan(spec, order="runs", aligned_flush=True, umc=True)
+    slots, plan = cores.lean_plan(spec, order="runs", aligned_flush=True, umc=True, chain_f=False)
     assert "u" not in slots.itab and min(slots.c) == -8 * n
     got, traces = emulate_lean_block(spec, slots, plan, q, qd, u)
     assert not np.isnan(got).any() and relerr(got, ref)[0] < 5e-6
@@ -188,6 +188,23 @@ def test_lean_inverse_dynamics_gradient_block_matches_oracle(use_qdd, robots, ta
         assert [d for (d, _) in tr.outputs].count("barrier") == 1
         assert tr.max_live()[0] <= 128
     assert 4 * 64 * (slots.count + cores.LEAN_WAVES * 34) <= 160 * 1024     # (100 KB: one block of 8 x 256 registers fills a CU anyway)
+
+
+def test_lean_runs_walked_towards_the_root_reuse_the_childs_force(robots):
+    """chain_f (shipped in the forward-dynamics-gradient kernel): the d/dq run of a wave is walked from its deepest column towards
+    the root, and a column whose child was finished just before takes the child's accumulated force from registers instead of walking
+    the child's subtree again -- fewer instructions, same outputs (test_lean_block_matches_oracle runs with it), no more live values."""
+    spec = RobotSpec(robots("atlas30"))
+    work = {}
+    for chain in (False, True):
+        slots, plan = cores.lean_plan(spec, chain_f=chain)
+        traces = [cores.core_gradient_recompute(spec, "fd", cols=items, coop=(role, slots)) for (role, items) in plan]
+        work[chain] = (sum(cores.lean_arith(tr) for tr in traces), max(tr.max_live()[0] for tr in traces))
+        if chain:
+            for tr in traces:           # the d/dq block (row offsets below n*n) leaves from the top of the wave's run downwards
+                lo = [int(d.split(":")[2]) for (d, _) in tr.outputs if isinstance(d, str) and d.startswith("flush:") and int(d.split(":")[2]) < spec.n ** 2]
+                assert not lo or (lo[0] >= max(lo) - 32 and lo[-1] <= min(lo) + 32)
+    assert work[True][0] < 0.95 * work[False][0] and work[True][1] <= work[False][1] + 8, work
 
 
 def test_lean_cores_stay_within_half_a_simd(robots):

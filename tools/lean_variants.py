@@ -32,9 +32,11 @@ VARIANTS = {
     # a column whose two halves are one wave's: two passes (d/dq recursion, d/dqd recursion) instead of one carrying both
     "atlas30_sep": dict(experimental={"lean_plan": {"separate_halves": True}}),
     # inputs straight from the configuration's row + u - c published instead of c and u (same planner, same sink)
-    "atlas30_rl": dict(experimental={"lean_row_loads": True, "lean_plan": {"umc": True}}),
+    "atlas30_rl": dict(experimental={"lean_plan": {"umc": True, "order": "lpt", "aligned_flush": False, "chain_f": False}}),
     # ... + contiguous runs per wave + output cut at the 32-byte sectors of the row (AlignedPieces, grid_out_pieces)
-    "atlas30_al": dict(experimental={"lean_row_loads": True, "lean_plan": {"umc": True, "order": "runs", "aligned_flush": True}}),
+    "atlas30_al": dict(experimental={"lean_plan": {"chain_f": False}}),
+    # the accumulated force of the column finished last reused by its parent's column (runs walked towards the root): off
+    "atlas30_nochain": dict(experimental={"lean_plan": {"chain_f": False}, "lean_id_plan": {"chain_f": False}}),
     "atlas30_runs2": dict(experimental={"lean_plan": {"order": "runs"}}),
     "atlas30_runs_pph": dict(experimental={"lean_plan": {"order": "runs", "products_per_half": True}}),
     # both halves of a column in one wave: one recursion, the two -Minv dc products one after the other (n accumulators instead of 2 n)

@@ -38,7 +38,7 @@ def main():
         data = json.load(fh)
     # which (robot, batch) a kernel name belongs to: the bench runs iiwa7 at 16384 and atlas30 at 16384 (secondary)
     for kname in sorted(set(fetch) & set(write)):
-        m = re.search(r"grid_(\w+?)::(forward_dynamics_gradient_kernel\w*)", kname)
+        m = re.search(r"grid_(\w+?)::((?:forward|inverse)_dynamics_gradient_kernel\w*)", kname)
         if not m:
             continue
         robot, kernel = m.group(1), m.group(2)

@@ -21,8 +21,16 @@ want bench && { step bench_atlas131 bash -c "timeout -k 10 300 python bench.py -
 want bench && { step bench_quad bash -c "timeout -k 10 300 python bench.py --robot quad12 --batch 16384 --all-kernels --steps 50 --warmup 5 > $out/bench_quad12_16384.json 2>> $out/bench.err"; }
 want bench && { step bench_atlas_mixed bash -c "timeout -k 10 300 python bench.py --robot atlas30 --batch 16384 --precision mixed --no-secondary --steps 50 --warmup 5 > $out/bench_atlas30_16384_mixed.json 2>> $out/bench.err"; }
 want prof && { step kt      bash -c "timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $out/kt --output-format csv -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline > $out/kt.log 2>&1"; }
-want prof && { step fetch   bash -c "timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/fetch --output-format csv -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline > $out/fetch.log 2>&1"; }
-want prof && { step write   bash -c "timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/write --output-format csv -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline > $out/write.log 2>&1"; }
+# HBM traffic counters: one workload per pass (tools/pmc_traffic.py keys an entry by robot, batch and kernel), FETCH_SIZE and WRITE_SIZE
+# in separate passes, --kernel-trace only next to --pmc
+pmc() { name=$1; ctr=$2; shift 2; step pmc_${ctr}_$name bash -c "timeout -k 10 300 rocprofv3 --pmc $ctr --kernel-trace -d $out/pmc_${ctr}_$name --output-format csv -- $* > $out/pmc_${ctr}_$name.log 2>&1"; }
+for ctr in FETCH_SIZE WRITE_SIZE; do
+want prof && pmc iiwa7_16384 $ctr python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-secondary
+want prof && pmc atlas30_16384 $ctr python3 bench.py --robot atlas30 --batch 16384 --steps 20 --warmup 2 --no-cpu-baseline --no-secondary
+want prof && pmc atlas30_65536 $ctr python3 bench.py --robot atlas30 --batch 65536 --steps 10 --warmup 2 --no-cpu-baseline --no-secondary
+want prof && pmc atlas30_dID_16384 $ctr python3 tools/run_alg.py atlas30 3 16384 1 0 10
+want prof && pmc atlas30_dID_65536 $ctr python3 tools/run_alg.py atlas30 3 65536 1 0 6
+done
 want prof2 && { step kt_headline bash -c "timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/kt_headline --output-format csv -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-secondary > $out/kt_headline.log 2>&1"; }
 want sweeps && { step wave_errors bash -c "timeout -k 10 300 python tests/gpu_checks/wave_small_batch_errors.py > $out/wave_small_batch_errors.txt 2>&1"; }
 want sweeps && { step precision_fp32  bash -c "timeout -k 10 400 python tests/gpu_checks/precision_report.py fp32 > $out/precision_report_fp32.txt 2>&1"; }
