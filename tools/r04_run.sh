@@ -32,6 +32,12 @@ want prof && pmc atlas30_dID_16384 $ctr python3 tools/run_alg.py atlas30 3 16384
 want prof && pmc atlas30_dID_65536 $ctr python3 tools/run_alg.py atlas30 3 65536 1 0 6
 done
 want prof2 && { step kt_headline bash -c "timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/kt_headline --output-format csv -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-secondary > $out/kt_headline.log 2>&1"; }
+kt() { name=$1; shift; step kt_$name bash -c "timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/kt_$name --output-format csv -- $* > $out/kt_$name.log 2>&1"; }
+want prof2 && kt atlas30_16384 python3 bench.py --robot atlas30 --batch 16384 --steps 100 --warmup 10 --no-cpu-baseline --no-secondary
+want prof2 && kt atlas30_65536 python3 bench.py --robot atlas30 --batch 65536 --steps 50 --warmup 5 --no-cpu-baseline --no-secondary
+want prof2 && kt atlas30_dID_16384 python3 tools/run_alg.py atlas30 3 16384 1 0 300
+want prof2 && kt atlas30_dID_65536 python3 tools/run_alg.py atlas30 3 65536 1 0 100
+want sweeps && { step lean_id_sweep bash -c "timeout -k 10 300 python tools/lean_id_sweep.py atlas30 > $out/lean_id_sweep.txt 2>&1"; }
 want sweeps && { step wave_errors bash -c "timeout -k 10 300 python tests/gpu_checks/wave_small_batch_errors.py > $out/wave_small_batch_errors.txt 2>&1"; }
 want sweeps && { step precision_fp32  bash -c "timeout -k 10 400 python tests/gpu_checks/precision_report.py fp32 > $out/precision_report_fp32.txt 2>&1"; }
 want sweeps && { step precision_mixed bash -c "timeout -k 10 400 python tests/gpu_checks/precision_report.py mixed > $out/precision_report_mixed.txt 2>&1"; }
