@@ -162,6 +162,7 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, SpatialAlgebraEmitMixin, Al
         self.lean_min_joints = int(exp["lean_min_joints"])
         self.in_rows = bool(exp["in_rows"])
         self.split_half_columns = bool(exp["split_half_columns"])
+        self.lean_wave_max_k, self.lean_id_wave_max_k = 768, 1408     # batch sizes from which the lean kernels beat the wave-per-configuration kernels
         self.lean_id_auto_min_tiles = 1    # register-lean inverse-dynamics-gradient kernel: automatic from this many tiles on
         self.lean_auto_min_tiles = 1       # register-lean 8-wave kernel: automatic from this many tiles on (0: on request) -- measured faster than
                                            # the 4-wave kernel at every batch size (profiles/r04/lean_sweep.txt)

@@ -1887,6 +1887,7 @@ class AlgorithmEmitMixin:
         if prep is None:
             self.gen_add_code_line("const int FD_DU_LEAN_WAVES = 0; // no register-lean tile-cooperative kernel for this robot / arithmetic")
             self.gen_add_code_line("const int FD_DU_LEAN_AUTO_MIN_TILES = 0;")
+            self.gen_add_code_line("const int FD_DU_LEAN_WAVE_MAX_K = 0;")
         else:
             slots, plan, stage, lds_elems = prep
             self.gen_add_code_line("const int FD_DU_LEAN_WAVES = %d; // wavefronts per block of the register-lean tile-cooperative kernel (block = %d threads, one tile)" % (W, W * WAVE))
@@ -1895,6 +1896,9 @@ class AlgorithmEmitMixin:
             self.gen_add_code_line("const int FD_DU_LEAN_AUTO_MIN_TILES = %d; // automatic choice of the register-lean kernel from this many tiles on (0: only on request)" % self.lean_auto_min_tiles)
             self.gen_add_code_line("const int FD_DU_LEAN_SHARED_MEM_COUNT = %d; // dynamic LDS in T elements: %d staging regions of %d + %d exchange slots x 64 lanes"
                                    % (lds_elems, W, stage, slots.count))
+            # where this kernel overtakes the wave-per-configuration kernel (one block per configuration, 512 resident at a time): Atlas-30
+            # wave 20.5 us at K = 512, 39.7 at 1024 against 34.9 / 35.3 us here (profiles/r04/latency_all_atlas30_fp32.txt)
+            self.gen_add_code_line("const int FD_DU_LEAN_WAVE_MAX_K = %d; // with this kernel in the library the wave-per-configuration kernel is chosen automatically only up to this batch size (0: FD_DU_WAVE_AUTO_MAX_K alone decides)" % self.lean_wave_max_k)
         self.gen_add_code_lines(["template <typename T>", "__host__ inline",
                                  "bool forward_dynamics_gradient_lean_launch(T *d_df_du, const T *d_q_qd_u, const int stride_q_qd_u, const robotModel<T> *d_robotModel, "
                                  "const T gravity, const int num_timesteps, int tile_blocks, hipStream_t stream);", ""])
@@ -2051,12 +2055,15 @@ class AlgorithmEmitMixin:
         if prep is None:
             self.gen_add_code_line("const int ID_DU_LEAN_WAVES = 0; // no register-lean inverse-dynamics-gradient kernel for this robot / arithmetic")
             self.gen_add_code_line("const int ID_DU_LEAN_AUTO_MIN_TILES = 0;")
+            self.gen_add_code_line("const int ID_DU_LEAN_WAVE_MAX_K = 0;")
         else:
             slots, plan, stage, lds_elems = prep
             self.gen_add_code_line("const int ID_DU_LEAN_WAVES = %d; // wavefronts per block of inverse_dynamics_gradient_kernel_coop8 (block = %d threads, one tile)" % (W, W * WAVE))
             self.gen_add_code_line("const int ID_DU_LEAN_AUTO_MIN_TILES = %d; // automatic choice of that kernel from this many tiles on (0: only on request)" % self.lean_id_auto_min_tiles)
             self.gen_add_code_line("const int ID_DU_LEAN_SHARED_MEM_COUNT = %d; // dynamic LDS in T elements: %d staging regions of %d + %d table slots x 64 lanes"
                                    % (lds_elems, W, stage, slots.count))
+            # Atlas-30: wave-per-configuration 15.9 us at K = 1024, 34.5 at 2048 against 23.8 / 24.7 us here (same file)
+            self.gen_add_code_line("const int ID_DU_LEAN_WAVE_MAX_K = %d; // the wave-per-configuration kernel automatically only up to this batch size (0: ID_DU_WAVE_AUTO_MAX_K alone decides)" % self.lean_id_wave_max_k)
         self.gen_add_code_line("")
 
     def gen_inverse_dynamics_gradient_lean(self, use_thread_group=False):

@@ -264,7 +264,7 @@ static bool use_coop(const grid_handle *h, int alg, int K, const float *d_qdd, c
 // columns / Minv columns / joints of a group of base-rooted trees.  A configuration then takes as long as its longest group's chain
 // ON 64 LANES, not as long as the whole chain on one lane: the small-batch path.  Automatic up to <ALG>_WAVE_AUTO_MAX_K configurations
 // (generated header: large robots; the measurements are quoted there); an explicit choice of another variant wins.
-static int wave_auto_max_k(int alg) {
+static int wave_auto_max_k_header(int alg) {
     switch (alg) {
     case GRID_ALG_ID: return G::ID_WAVE_AUTO_MAX_K;
     case GRID_ALG_MINV: return G::MINV_WAVE_AUTO_MAX_K;
@@ -273,6 +273,13 @@ static int wave_auto_max_k(int alg) {
     case GRID_ALG_FD_DU: return G::FD_DU_WAVE_AUTO_MAX_K;
     default: return 0;
     }
+}
+// ... capped where the library has a register-lean tile-cooperative kernel that is faster from a smaller batch on (<ALG>_LEAN_WAVE_MAX_K)
+static int wave_auto_max_k(int alg) {
+    const int k = wave_auto_max_k_header(alg);
+    const int cap = (alg == GRID_ALG_FD_DU && G::FD_DU_LEAN_WAVES > 0) ? G::FD_DU_LEAN_WAVE_MAX_K
+                  : (alg == GRID_ALG_ID_DU && G::ID_DU_LEAN_WAVES > 0) ? G::ID_DU_LEAN_WAVE_MAX_K : 0;
+    return (cap > 0 && cap < k) ? cap : k;
 }
 static bool wave_available(int alg) { return alg >= 0 && alg <= 4 && G::FD_DU_WAVE_WAVES > 0; }
 static bool use_wave(const grid_handle *h, int alg, int K, const float *d_qdd, const float *d_Minv, int blocks = 0, int threads = 0) {

@@ -137,7 +137,8 @@ int grid_kernel_attributes_lean(int alg, int *out);
  * whole chain on one lane (Atlas-30, K = 64, us per launch, lanes -> waves: RNEA 9.6 -> 5.2, Minv 31 -> 7.6, FD 28 -> 10.1,
  * RNEA gradient 37 -> 12.7, FD gradient 55 -> 19.9).  grid_wave_available: 1 if emitted for `alg` (every algorithm of a robot that
  * has the kernels; none in all-double builds).  grid_set_wave: 0 = automatic (default: batches up to <ALG>_WAVE_AUTO_MAX_K of the
- * generated header, which quotes the measurements behind each constant -- and only for calls that leave the launch shape to the
+ * generated header, which quotes the measurements behind each constant, capped at <ALG>_LEAN_WAVE_MAX_K where the library has a
+ * register-lean tile-cooperative kernel that is faster from a smaller batch on -- and only for calls that leave the launch shape to the
  * library, blocks <= 0 and threads <= 0: a caller's blocks x threads means blocks of `threads` CONFIGURATIONS, the reference's launch
  * shape, and keeps the lane-per-configuration kernels), 1 = never, 2 = always (`blocks` is then the number of configurations in
  * flight, one block each).  grid_get_wave: 1 if a call with `num_timesteps` and the default launch shape would dispatch it (it takes

@@ -325,6 +325,10 @@ def test_automatic_choice_follows_the_header_thresholds(robot, tables):
         text = fh.read()
     names = {host.ALG_ID: "ID", host.ALG_MINV: "MINV", host.ALG_FD: "FD", host.ALG_ID_DU: "ID_DU", host.ALG_FD_DU: "FD_DU"}
     limit = {a: int(re.search(r"const int %s_WAVE_AUTO_MAX_K = (\d+);" % nm, text).group(1)) for a, nm in names.items()}
+    for a, nm in names.items():         # ... capped where a register-lean tile-cooperative kernel takes over earlier (<ALG>_LEAN_WAVE_MAX_K)
+        m = re.search(r"const int %s_LEAN_WAVE_MAX_K = (\d+);" % nm, text)
+        if m and int(m.group(1)) > 0:
+            limit[a] = min(limit[a], int(m.group(1)))
     T = tables(robot)
     with host.GridHandle(robot, device=0, precision=host.DEFAULT_PRECISION) as h:
         n = h.n
@@ -334,7 +338,7 @@ def test_automatic_choice_follows_the_header_thresholds(robot, tables):
                 assert not h.get_wave(a, 1) and not h.get_wave(a, 64)
             else:
                 assert h.get_wave(a, 1) and h.get_wave(a, lim) and not h.get_wave(a, lim + 1)
-        assert limit[host.ALG_FD_DU] == (1024 if n > 12 else 0)
+        assert limit[host.ALG_FD_DU] == (768 if n > 12 else 0)
         h.set_split(host.ALG_FD_DU, 1)                               # an explicit choice of another variant wins
         assert not h.get_wave(host.ALG_FD_DU, 64)
         h.set_split(host.ALG_FD_DU, 0)
