@@ -2031,6 +2031,9 @@ class AlgorithmEmitMixin:
         if n < self.lean_min_joints or self.precision != "fp32" or (self.grad_schedule != "recompute" and n > 12):
             return None
         slots, plan = cores.lean_plan_id(self.spec, False, W, **self.lean_id_plan_options)
+        if isinstance(self.lean_probe, str) and self.lean_probe.startswith("id_only:"):       # (experiment: one wave keeps its columns)
+            keep = int(self.lean_probe.split(":")[1])
+            plan = [(role, items if w == keep else []) for w, (role, items) in enumerate(plan)]
         stage = WAVE * 34
         lds_elems = W * stage + WAVE * slots.count
         if 4 * lds_elems > 160 * 1024:
@@ -2116,26 +2119,45 @@ class AlgorithmEmitMixin:
             "const int nblocks = grid_num_blocks();",
             "const int bid = grid_block_id();",
             "if (grid_block_threads() != %d){return;}    // (the launcher guarantees it; a wrong shape must not deadlock the barrier)" % (W * WAVE),
-            "for (int k0 = bid*GRID_WAVE_SIZE; k0 < NUM_TIMESTEPS; k0 += nblocks*GRID_WAVE_SIZE){",
         ])
-        self.indent_level += 1
-        self.gen_add_code_line("// every lane reads the few inputs its wave needs from its row: wave-uniform base of the tile + one 32-bit per-lane row offset")
-        self.gen_add_code_line("const T *s_q_qd = grid_opaque_uniform(d_q_qd + (size_t)k0*stride_q_qd);")
-        self.gen_add_code_line("const unsigned in_row = (unsigned)min(it.lane, NUM_TIMESTEPS - 1 - k0)*(unsigned)stride_q_qd*(unsigned)sizeof(T);")
-        self.gen_add_code_line("const unsigned xb = (unsigned)reinterpret_cast<unsigned long long>(s_xch) + (unsigned)sizeof(T)*it.lane;")
-        self.gen_add_code_line("const grid_in_lean<T> in = {s_q_qd, s_q_qd + %d, nullptr, s_xch, it.lane, xb, xb + 256u*GRID_WAVE_SIZE*(unsigned)sizeof(T), "
-                               "xb - 256u*GRID_WAVE_SIZE*(unsigned)sizeof(T), in_row};" % n)
-        self.gen_add_code_line("switch (it.wave_in_block){", True)
-        for w, cname in enumerate(names):
-            self.gen_add_code_line("case %d: {" % w, True)
-            self.gen_add_code_line("grid_out_pieces<T,%d> out = {s_wave, d_dc_du, k0, it.lane, it.W, NUM_TIMESTEPS};" % n_out)
-            self.gen_add_code_line("%s<T,C>(in, out, gravity);" % cname)
-            self.gen_add_code_line("break;")
+        setup = ["// every lane reads the few inputs its wave needs from its row: wave-uniform base of the tile + one 32-bit per-lane row offset",
+                 "const T *s_q_qd = grid_opaque_uniform(d_q_qd + (size_t)k0*stride_q_qd);",
+                 "const unsigned in_row = (unsigned)min(it.lane, NUM_TIMESTEPS - 1 - k0)*(unsigned)stride_q_qd*(unsigned)sizeof(T);",
+                 "const unsigned xb = (unsigned)reinterpret_cast<unsigned long long>(s_xch) + (unsigned)sizeof(T)*it.lane;",
+                 "const grid_in_lean<T> in = {s_q_qd, s_q_qd + %d, nullptr, s_xch, it.lane, xb, xb + 256u*GRID_WAVE_SIZE*(unsigned)sizeof(T), "
+                 "xb - 256u*GRID_WAVE_SIZE*(unsigned)sizeof(T), in_row};" % n]
+        loop = "for (int k0 = bid*GRID_WAVE_SIZE; k0 < NUM_TIMESTEPS; k0 += nblocks*GRID_WAVE_SIZE){"
+        sync = "grid_block_sync();     // the input table and the staging regions are rewritten by the next tile"
+        if self.lean_loop_per_role:
+            # one tile loop PER ROLE (the switch outside): what hipcc hoists out of a loop then belongs to one role, not to all eight
+            self.gen_add_code_line("switch (it.wave_in_block){", True)
+            for w, cname in enumerate(names):
+                self.gen_add_code_line("case %d: {" % w, True)
+                self.gen_add_code_line(loop, True)
+                self.gen_add_code_lines(setup)
+                self.gen_add_code_line("grid_out_pieces<T,%d> out = {s_wave, d_dc_du, k0, it.lane, it.W, NUM_TIMESTEPS};" % n_out)
+                self.gen_add_code_line("%s<T,C>(in, out, gravity);" % cname)
+                self.gen_add_code_line(sync)
+                self.gen_add_end_control_flow()
+                self.gen_add_code_line("break;")
+                self.gen_add_end_control_flow()
+            self.gen_add_code_line("default: break;")
             self.gen_add_end_control_flow()
-        self.gen_add_code_line("default: break;")
-        self.gen_add_end_control_flow()
-        self.gen_add_code_line("grid_block_sync();     // the input table and the staging regions are rewritten by the next tile")
-        self.gen_add_end_control_flow()
+        else:
+            self.gen_add_code_line(loop)
+            self.indent_level += 1
+            self.gen_add_code_lines(setup)
+            self.gen_add_code_line("switch (it.wave_in_block){", True)
+            for w, cname in enumerate(names):
+                self.gen_add_code_line("case %d: {" % w, True)
+                self.gen_add_code_line("grid_out_pieces<T,%d> out = {s_wave, d_dc_du, k0, it.lane, it.W, NUM_TIMESTEPS};" % n_out)
+                self.gen_add_code_line("%s<T,C>(in, out, gravity);" % cname)
+                self.gen_add_code_line("break;")
+                self.gen_add_end_control_flow()
+            self.gen_add_code_line("default: break;")
+            self.gen_add_end_control_flow()
+            self.gen_add_code_line(sync)
+            self.gen_add_end_control_flow()
         self.gen_add_end_function()
         self.gen_add_func_doc("Launch the register-lean tile-cooperative inverse-dynamics-gradient kernel (asynchronous, on `stream`)",
                               ["tile_blocks <= 0: one block per tile of 64 configurations (capped at 4*SUGGESTED_MAX_BLOCKS)"], [], None)
