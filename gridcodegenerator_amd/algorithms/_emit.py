@@ -1859,6 +1859,13 @@ class AlgorithmEmitMixin:
         self._lean_cache = None
         if n < self.lean_min_joints or self.precision != "fp32" or (self.grad_schedule != "recompute" and n > 12):
             return None
+        # (the LDS need is known before the plan, which costs ~2 n traced cores: a robot whose exchange region cannot fit skips it)
+        probe_slots = cores.CoopSlots(self.spec)
+        probe_slots.enable_lean(self.spec, umc=self.lean_plan_options.get("umc", True))
+        if 4 * (W * WAVE * (34 if self.lean_plan_options.get("aligned_flush", True) else n) + WAVE * probe_slots.count) > 160 * 1024:
+            self.note("no register-lean 8-wave tile-cooperative kernel (FD_DU_LEAN_WAVES = 0): exchange region + input table + 8 staging "
+                      "regions need %d KB of the CU's 160 KB of LDS" % ((W * WAVE * 34 + WAVE * probe_slots.count) * 4 // 1024))
+            return None
         slots, plan = cores.lean_plan(self.spec, W, **self.lean_plan_options)
         if self.lean_probe == "prefix":             # (experiment: phases 0-3 only -- what a tile costs before its first gradient column)
             for (role, items) in plan:

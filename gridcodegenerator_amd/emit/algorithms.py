@@ -15,7 +15,7 @@ reference's sparsity-compressed column storage (section 8(a) a8/a12 of SURVEY.md
 dictionaries keyed (joint, column) that only ever hold the structurally non-zero columns, and every
 6x6 product is specialised entry-by-entry by the tracer.
 """
-from .trace import P, V
+from .trace import P, Tracer, V
 
 _I3 = range(3)
 
@@ -545,6 +545,45 @@ def sym_minv_times_columns(tr, spec, entry, dc_lo, dc_hi, block=16):
             if need_kr:
                 acc_lo[k] = tr.fma(m, dc_lo[r], acc_lo[k]); acc_hi[k] = tr.fma(m, dc_hi[r], acc_hi[k])
     return [-x for x in acc_lo], [-x for x in acc_hi]
+
+
+def sym_minv_times_column_pair(tr, spec, entry, dc_a, dc_b, block=16):
+    """-Minv_sym @ dc for TWO gradient half-columns of one base-rooted tree at once: every upper-triangle entry of Minv is fetched
+    once for both (entry(r, k), r <= k, as in sym_minv_times_columns) and each multiply-add serves both columns as ONE packed
+    instruction (v_pk_fma_f32: accumulator pair += entry x (dc_a[k], dc_b[k])) -- half the LDS reads and half the vector
+    instructions of two separate products, in a kernel that is bound by vector-instruction issue.  Rows that only one column has
+    stay scalar (the pair folds).  dc_a / dc_b: {row: value}.  Returns (column a, column b), n values each."""
+    n = spec.n
+    zero = tr.zero()
+    rows = set(dc_a) | set(dc_b)
+    pair = {k: P(tr, dc_a.get(k, zero), dc_b.get(k, zero)) for k in rows}
+    acc = [P(tr, zero, zero) for _ in range(n)]
+    need = []
+    for k in range(n):
+        for r in range(k + 1):
+            need_rk = k in rows
+            need_kr = (r != k) and (r in rows)
+            if need_rk or need_kr:
+                need.append((r, k, need_rk, need_kr))
+    blocks = [need[i:i + block] for i in range(0, len(need), block)]
+    fetch = lambda blk: [entry(r, k) for (r, k, _, _) in blk]
+    pending = fetch(blocks[0]) if blocks else []
+    was = Tracer.use_packed
+    Tracer.use_packed = True
+    try:
+        for b, blk in enumerate(blocks):
+            vals = pending
+            pending = fetch(blocks[b + 1]) if b + 1 < len(blocks) else []
+            for (r, k, need_rk, need_kr), m in zip(blk, vals):
+                if m is None:
+                    continue
+                if need_rk:
+                    acc[r] = tr.fma(m, pair[k], acc[r])
+                if need_kr:
+                    acc[k] = tr.fma(m, pair[r], acc[k])
+    finally:
+        Tracer.use_packed = was
+    return [-x.lo for x in acc], [-x.hi for x in acc]
 
 
 def fd_grad_finish(tr, spec, Minv, dc, cols=None):

@@ -346,7 +346,7 @@ def lean_arith(tr, start=1, stop=None):
     """Arithmetic instructions + LDS reads of the live part of a trace between two node positions."""
     live = tr.live_nodes()
     stop = len(tr.nodes) if stop is None else stop
-    return sum(1 for k in range(start, stop) if live[k] and tr.nodes[k][0] in ("fma", "mul", "add", "rcp", "in"))
+    return sum(1 for k in range(start, stop) if live[k] and tr.nodes[k][0] in ("fma", "mul", "add", "rcp", "in", "pkfma", "pkmul", "pkadd"))
 
 
 def lean_barriers(tr):
@@ -354,7 +354,7 @@ def lean_barriers(tr):
 
 
 def lean_plan(spec, waves=LEAN_WAVES, max_parked=3, younger_speed=None, keep_x_below=0, columns_from_chain=False, order="runs",
-              products_per_half=False, separate_halves=False, umc=True, aligned_flush=True, chain_f=True):
+              products_per_half=False, separate_halves=False, umc=True, aligned_flush=True, chain_f=True, pair_products=False):
     """Who does what in a register-lean block of `waves` wavefronts (two per SIMD): returns (slots, [(LeanRole, [(column, half)])]).
 
     Phase 0 (input table): joints dealt round-robin.  Phase 1: the BACKWARD pass of the Minv recursion once per base-rooted tree -- the
@@ -381,6 +381,7 @@ def lean_plan(spec, waves=LEAN_WAVES, max_parked=3, younger_speed=None, keep_x_b
     slots.separate_halves = bool(separate_halves)
     slots.aligned_flush = bool(aligned_flush)
     slots.chain_f = bool(chain_f)
+    slots.pair_products = bool(pair_products)
     trees = sorted(base_trees(spec), key=lambda t: -t[1])
     big = list(range(trees[0][0], trees[0][0] + trees[0][1]))
     rest = [j for (f, m) in trees[1:] for j in range(f, f + m)]
@@ -1330,6 +1331,7 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
     tr.run_bases = []
     pass_halves = []        # (lean cores with separate_halves: the halves each pass of the column loop emits, in order)
     stream = None           # (lean cores with aligned_flush: AlignedPieces, set once the order of the half-columns is known)
+    pairing = {"role": [], "at": 0, "held": None}      # (lean cores with pair_products: per pass "first" | "second" | None; the held first column)
     if coop is not None:
         assert (kind == "fd" or lean) and not use_qdd_minv and not table and rollout is None
         role, slots = coop
@@ -1563,6 +1565,20 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
             dqd_half = saved_dqd.pop(col, None) or {k: dc[k][1] for k in rows}       # (computed ahead of the barriers when parked)
             halves = (pass_halves.pop(0) if pass_halves else want[col]) if want is not None else (0, 1)
             none = {k: tr.zero() for k in rows}
+            if pairing["role"]:
+                what = pairing["role"][pairing["at"]]
+                pairing["at"] += 1
+                h = halves[0]
+                vec = {k: dc[k][0] for k in rows} if h == 0 else {k: dqd_half[k] for k in rows}
+                if what == "first":
+                    pairing["held"] = (col, h, vec)        # (its n or fewer values wait in registers for the partner's recursion)
+                    return
+                if what == "second":
+                    (col_a, h_a, vec_a), pairing["held"] = pairing["held"], None
+                    out_a, out_b = alg.sym_minv_times_column_pair(tr, spec, lambda r, k: minv_entry(r, k), vec_a, vec)
+                    emit_run(col_a, h_a, out_a)
+                    emit_run(col, h, out_b)
+                    return
             if want is not None:
                 if len(halves) == 2 and getattr(coop[1], "products_per_half", False):
                     # both halves of a column in one wave: ONE recursion, but the two products one after the other -- n accumulators
@@ -1731,6 +1747,18 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
             order = [c_ for (c_, _) in passes]
             del pass_halves[:]
             pass_halves.extend(h_ for (_, h_) in passes)
+            if getattr(slots, "pair_products", False) and kind == "fd":
+                # consecutive passes of the same half and the same base-rooted tree share ONE product (alg.sym_minv_times_column_pair)
+                root = lambda j: j if spec.parent[j] == -1 else root(spec.parent[j])
+                role_of, i = [None] * len(passes), 0
+                while i + 1 < len(passes):
+                    (ca, ha), (cb, hb) = passes[i], passes[i + 1]
+                    if ha == hb and root(ca) == root(cb):
+                        role_of[i], role_of[i + 1] = "first", "second"
+                        i += 2
+                    else:
+                        i += 1
+                pairing["role"] = role_of
             seq = []                        # row offsets of the half-columns in the order they will be emitted
             halves_of = list(pass_halves) if pass_halves else [tuple(sorted(want[c_])) for c_ in order]
             for c_, hs in zip(order, halves_of):

@@ -207,6 +207,22 @@ def test_lean_runs_walked_towards_the_root_reuse_the_childs_force(robots):
     assert work[True][0] < 0.95 * work[False][0] and work[True][1] <= work[False][1] + 8, work
 
 
+def test_lean_block_with_paired_products_matches_oracle(robots, tables):
+    """lean_plan(pair_products=True) -- measured slower on the GPU and not shipped (profiles/r04/exp_pair_products.txt), kept as an
+    option: two half-columns of one tree share one -Minv dc product with packed multiply-adds; same outputs, fewer instructions."""
+    from oracle import rbd_oracle as O
+    spec = RobotSpec(robots("atlas30"))
+    n, K = spec.n, 2
+    q, qd, u = (a.astype(np.float64) for a in make_inputs(n, K, 67))
+    ref = O.fd_grad(tables("atlas30"), q, qd, u)
+    ref = np.concatenate([O.flat_colmajor(ref[:, :, :n]), O.flat_colmajor(ref[:, :, n:])], axis=1)
+    slots, plan = cores.lean_plan(spec, pair_products=True)
+    got, traces = emulate_lean_block(spec, slots, plan, q, qd, u)
+    assert not np.isnan(got).any() and relerr(got, ref)[0] < 5e-6
+    packed = sum(1 for tr in traces for k, live in enumerate(tr.live_nodes()) if live and k and tr.nodes[k][0] == "pkfma")
+    assert packed > 2000
+
+
 def test_lean_cores_stay_within_half_a_simd(robots):
     """The point of the exercise: the values a lean core holds at once (creation-order emission, the order the kernel is emitted in)
     stay far below 256 -- the 4-wave cores of the same robot hold 280-390 in their prologue alone -- and the block's LDS fits the CU."""

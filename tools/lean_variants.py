@@ -47,6 +47,8 @@ VARIANTS = {
     # ... + the output cut at the 32-byte sectors of the row (AlignedPieces, grid_out_pieces), u - c published: the shipped kernel without chain_f
     "atlas30_al": dict(experimental={"lean_plan": {"chain_f": False}}),
     # chain_f (the accumulated force of the column finished last reused by its parent's column) in BOTH lean kernels / in neither
+    # two half-columns of one tree share ONE -Minv dc product: every Minv entry read once for both, packed multiply-adds (v_pk_fma_f32)
+    "atlas30_pair": dict(experimental={"lean_plan": {"pair_products": True}}),
     "atlas30_chain_both": dict(experimental={"lean_id_plan": {"chain_f": True}}),
     "atlas30_nochain": dict(experimental={"lean_plan": {"chain_f": False}, "lean_id_plan": {"chain_f": False}}),
     # (scheduling fences every N statements apply to every core of the header: such a variant recompiles all 26 kernels -- not registered)
