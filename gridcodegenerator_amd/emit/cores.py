@@ -1642,7 +1642,6 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
         if lean and kind == "id":
             # register-lean inverse-dynamics-gradient core: only the block's input table (sin, cos, qd and, with use_qdd, the given
             # qdd in the qdd slots) and ONE barrier in front of the gradient half-columns
-            assert not tr.mixed, "the register-lean cores exist in the fp32 arithmetic only"
             qdd_in = [tr.inp("in.qdd(%d)" % j) for j in range(n)] if use_qdd else None
             for j in role.joints:
                 if trig[j] is not None:
@@ -1656,7 +1655,8 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
             tr.barrier()
             qdd = [tr.zero()] * n if use_qdd else None       # (placeholders: touch() reads the published qdd of every joint it visits)
         elif lean:
-            assert not tr.mixed, "the register-lean cores exist in the fp32 arithmetic only"
+            # (mixed arithmetic: the Minv recursion -- alg.minv_backward_lean / minv_forward_lean -- and the qdd rows run in double
+            #  INSIDE the waves; what crosses the block's LDS -- U, 1/D, the backward-pass entries, Minv, c, qdd -- crosses as float)
             # ---- phase 0: this wave's share of the block's input table, then B0 (everything below reads inputs through touch())
             for j in role.joints:
                 if trig[j] is not None:
@@ -1713,7 +1713,9 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
                         if k not in umc:
                             umc[k] = tr.xch_get(slots.c[k]) if slots.lean_umc else tr.xch_get(itab["u"][k]) - tr.xch_get(slots.c[k])
                         terms.append((m, umc[k]))
-                    tr.xch_put(slots.qdd[r], tr.dot(terms))
+                    with tr.mixed_region():
+                        row = tr.dot(terms)
+                    tr.xch_put(slots.qdd[r], row)
             tr.barrier()
             qdd = [tr.zero()] * n       # (placeholders: touch() reads the published qdd of every joint it visits)
         else:
