@@ -428,7 +428,9 @@ def main():
                      ("C2_iiwa7_batch1024_inverse_dynamics_gradient", "iiwa7", 1024, min(args.steps, 50), min(args.warmup, 5), ID_DU),
                      ("C3_iiwa7_batch16384_forward_dynamics", "iiwa7", 16384, min(args.steps, 50), min(args.warmup, 5), FD),
                      ("C4_atlas30_batch65536_forward_dynamics_gradient", "atlas30", 65536, min(args.steps, 25), min(args.warmup, 3), FD_DU),
-                     ("C4_atlas30_batch65536_inverse_dynamics_gradient", "atlas30", 65536, min(args.steps, 25), min(args.warmup, 3), ID_DU)]
+                     ("C4_atlas30_batch65536_inverse_dynamics_gradient", "atlas30", 65536, min(args.steps, 25), min(args.warmup, 3), ID_DU),
+                     # C5 (Atlas-30, 1 048 576 configurations over 8 GPUs) as ONE GPU sees it: its shard of 131 072
+                     ("C5_atlas30_batch131072_one_shard_of_8", "atlas30", 131072, min(args.steps, 10), min(args.warmup, 2), FD_DU)]
         if world > 1:
             plan.append(("atlas30_batch131072_per_gpu", "atlas30", 131072, min(args.steps, 10), min(args.warmup, 2), FD_DU))
         for (key, robot, K, steps, warmup, alg) in plan:
