@@ -77,6 +77,7 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, SpatialAlgebraEmitMixin, Al
         wave_occupancy=1,       # wave-per-configuration kernels: waves per SIMD the register allocation must leave room for (2: <= 256 registers)
         lean_read_ahead=0,      # register-lean 8-wave kernel: LDS reads issued this many instructions ahead of their use (Tracer.emit read_ahead)
         lean_loop_per_role=False,   # register-lean inverse-dynamics-gradient kernel: one tile loop per role (switch outside) instead of one switch per tile
+        lean_mixed=False,       # mixed arithmetic: also build the register-lean forward-dynamics-gradient kernel (see algorithms/_emit.py: _lean_prepare)
         lean_min_joints=13,     # register-lean 8-wave kernels for robots with at least this many joints
         lean_id_plan={},        # register-lean inverse-dynamics-gradient kernel: keyword overrides of cores.lean_plan_id (chain_f)
         lean_plan={},           # register-lean 8-wave kernel: keyword overrides of cores.lean_plan (younger_speed, max_parked)
@@ -161,6 +162,7 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, SpatialAlgebraEmitMixin, Al
         self.lean_id_plan_options = dict(exp["lean_id_plan"])
         self.lean_read_ahead = int(exp["lean_read_ahead"])
         self.lean_min_joints = int(exp["lean_min_joints"])
+        self.lean_mixed = bool(exp["lean_mixed"])
         self.lean_loop_per_role = bool(exp["lean_loop_per_role"])
         self.in_rows = bool(exp["in_rows"])
         self.split_half_columns = bool(exp["split_half_columns"])

@@ -1857,7 +1857,12 @@ class AlgorithmEmitMixin:
         n = self.spec.n
         W = cores.LEAN_WAVES
         self._lean_cache = None
-        if n < self.lean_min_joints or self.precision != "fp32" or (self.grad_schedule != "recompute" and n > 12):
+        # fp32 only.  The cores accept the mixed arithmetic (Minv passes and qdd rows in double inside the waves, float across LDS;
+        # experimental lean_mixed=True builds it into the mixed library, on request: grid_set_coop mode 3), but what crosses LDS as
+        # float gives the double recursion's accuracy away: Atlas-30 dFD 1.7-8.1e-6 against 0.5-1.1e-6 for the 4-wave mixed kernel and
+        # 3.0e-6-1.1e-5 for this kernel in fp32, at 50.9 us against 44.4 (profiles/r04/mixed_lean_report.txt)
+        if (n < self.lean_min_joints or (self.precision != "fp32" and not (self.precision == "mixed" and self.lean_mixed))
+                or (self.grad_schedule != "recompute" and n > 12)):
             return None
         # (the LDS need is known before the plan, which costs ~2 n traced cores: a robot whose exchange region cannot fit skips it)
         probe_slots = cores.CoopSlots(self.spec)
@@ -1900,12 +1905,15 @@ class AlgorithmEmitMixin:
             self.gen_add_code_line("const int FD_DU_LEAN_WAVES = %d; // wavefronts per block of the register-lean tile-cooperative kernel (block = %d threads, one tile)" % (W, W * WAVE))
             # measured against the 4-wave kernel (profiles/r04/lean_sweep.txt, Atlas-30, us per launch, 4 waves -> 8 waves): K = 64 54.3 -> 40.0,
             # 4096 60.8 -> 47.9, 16384 67.0 -> 52.8, 32768 130.6 -> 106.7, 65536 306.9 -> 290.8, 131072 624 -> 568: every batch size
-            self.gen_add_code_line("const int FD_DU_LEAN_AUTO_MIN_TILES = %d; // automatic choice of the register-lean kernel from this many tiles on (0: only on request)" % self.lean_auto_min_tiles)
+            # mixed arithmetic: the Minv passes and the qdd rows run in double inside the waves, but what crosses LDS is float -- faster
+            # than the 4-wave kernel and less accurate than it: there only on request (grid_set_coop mode 3)
+            self.gen_add_code_line("const int FD_DU_LEAN_AUTO_MIN_TILES = %d; // automatic choice of the register-lean kernel from this many tiles on (0: only on request)"
+                                   % (self.lean_auto_min_tiles if self.precision == "fp32" else 0))
             self.gen_add_code_line("const int FD_DU_LEAN_SHARED_MEM_COUNT = %d; // dynamic LDS in T elements: %d staging regions of %d + %d exchange slots x 64 lanes"
                                    % (lds_elems, W, stage, slots.count))
             # where this kernel overtakes the wave-per-configuration kernel (one block per configuration, 512 resident at a time): Atlas-30
             # wave 20.5 us at K = 512, 39.7 at 1024 against 34.9 / 35.3 us here (profiles/r04/latency_all_atlas30_fp32.txt)
-            self.gen_add_code_line("const int FD_DU_LEAN_WAVE_MAX_K = %d; // with this kernel in the library the wave-per-configuration kernel is chosen automatically only up to this batch size (0: FD_DU_WAVE_AUTO_MAX_K alone decides)" % self.lean_wave_max_k)
+            self.gen_add_code_line("const int FD_DU_LEAN_WAVE_MAX_K = %d; // with this kernel in the library the wave-per-configuration kernel is chosen automatically only up to this batch size (0: FD_DU_WAVE_AUTO_MAX_K alone decides)" % (self.lean_wave_max_k if self.precision == "fp32" else 0))
         self.gen_add_code_lines(["template <typename T>", "__host__ inline",
                                  "bool forward_dynamics_gradient_lean_launch(T *d_df_du, const T *d_q_qd_u, const int stride_q_qd_u, const robotModel<T> *d_robotModel, "
                                  "const T gravity, const int num_timesteps, int tile_blocks, hipStream_t stream);", ""])
@@ -2035,8 +2043,8 @@ class AlgorithmEmitMixin:
             return self._lean_id_cache
         n, W = self.spec.n, cores.LEAN_WAVES
         self._lean_id_cache = None
-        if n < self.lean_min_joints or self.precision != "fp32" or (self.grad_schedule != "recompute" and n > 12):
-            return None
+        if n < self.lean_min_joints or self.precision not in ("fp32", "mixed") or (self.grad_schedule != "recompute" and n > 12):
+            return None             # (mixed: this kernel has no double part -- the same arithmetic as in the fp32 library)
         slots, plan = cores.lean_plan_id(self.spec, False, W, **self.lean_id_plan_options)
         if isinstance(self.lean_probe, str) and self.lean_probe.startswith("id_only:"):       # (experiment: one wave keeps its columns)
             keep = int(self.lean_probe.split(":")[1])
