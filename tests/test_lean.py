@@ -400,3 +400,28 @@ def test_lean_inverse_dynamics_gradient_full_size_atlas30_65536(tables):
         h.inverse_dynamics_gradient_device(d_out_p.data_ptr(), d_in_p.data_ptr(), 3 * n, K)
         h.synchronize()
         assert bool(torch.equal(d_out_p, d_out[perm]))
+
+
+@pytest.mark.gpu
+def test_mixed_library_has_the_lean_inverse_dynamics_gradient_only(tables):
+    """The mixed-arithmetic Atlas-30 library: its inverse-dynamics gradient has no double part, so the register-lean kernel is in it and
+    automatic (same numbers as the fp32 library's, bit for bit); its forward-dynamics gradient keeps the 4-wave kernel (the lean block
+    in the mixed arithmetic was measured and not shipped: profiles/r04/mixed_lean_report.txt)."""
+    import torch
+    from gridcodegenerator_amd import host
+    from test_gpu_parity import TOL_BY_PRECISION, oracle_all, pack
+    T = tables("atlas30")
+    with host.GridHandle("atlas30", device=0, precision="mixed") as hm, host.GridHandle("atlas30", device=0, precision="fp32") as hf:
+        n, K = hm.n, 700
+        assert hm.lean_available(host.ALG_ID_DU) and not hm.lean_available(host.ALG_FD_DU)
+        hm.set_wave(host.ALG_ID_DU, 1); hf.set_wave(host.ALG_ID_DU, 1)
+        assert hm.get_coop(host.ALG_ID_DU, K) == 2 and hm.get_coop(host.ALG_FD_DU, 16384) == 1
+        q, qd, u = make_inputs(n, K, 123)
+        d_in = torch.from_numpy(pack(q, qd, u)).cuda()
+        outs = []
+        for h in (hm, hf):
+            o = torch.zeros((K, 2 * n * n), dtype=torch.float32, device="cuda")
+            h.inverse_dynamics_gradient_device(o.data_ptr(), d_in.data_ptr(), 3 * n, K); h.synchronize()
+            outs.append(o.cpu().numpy())
+        assert np.array_equal(outs[0], outs[1])
+        assert relerr(outs[0], oracle_all(T, q, qd, u)["dc_du_noqdd"])[0] < TOL_BY_PRECISION["mixed"]["atlas30"]["dc_du"]
