@@ -442,6 +442,7 @@ def lean_plan(spec, waves=LEAN_WAVES, max_parked=3, younger_speed=None, keep_x_b
     for w, role in enumerate(roles):
         role.joints = [j for j in range(n) if j % waves == w]
         role.qdd_rows = [j for j in range(n) if j % waves == w]
+    lean_partial_layout(spec, slots, roles)
 
     def phase_costs(role):
         tr = probe(role, [(n - 1, 1)])
@@ -494,6 +495,30 @@ def lean_plan(spec, waves=LEAN_WAVES, max_parked=3, younger_speed=None, keep_x_b
     plan = [(roles[w], sorted(items[w])) for w in range(waves)]
     slots.lean_model = dict(phase1=[p1 for (p1, _) in ph], phase2=[p2 for (_, p2) in ph], t_b1=t_b1, post=[load[w] / speed[w] for w in range(waves)])
     return slots, plan
+
+
+def lean_partial_layout(spec, slots, roles):
+    """Mixed arithmetic on the lean block: qdd = Minv (u - c) must come from the UNROUNDED Minv (from the float copy in LDS the
+    gradient loses what the double recursion bought: profiles/r04/mixed_lean_report.txt).  Every wave therefore folds the final
+    entries of its forward-pass columns into partial sums of qdd in double while they are still in registers, and publishes them
+    as float pairs (hi, lo) after the forward pass -- in the staging regions, where U, 1/D and u - c are dead by then.  Lays out:
+    role.index; slots.partials[w] = (first pair, rows the wave contributes to); slots.root_lo[(root, k)] = word for the low part of
+    a base joint's row of Minv (final in the backward pass already, published there as hi + lo)."""
+    n = spec.n
+    slots.partials, off = {}, 0
+    for w, role in enumerate(roles):
+        role.index = w
+        rows = sorted(set(k for k in role.minv_cols) | set(r for k in role.minv_cols for r in range(n) if (r, k) in slots.minv and r <= k))
+        slots.partials[w] = (off, rows)
+        off += len(rows)
+    slots.partial_pairs = off
+    slots.root_lo, at = {}, 8 * n
+    for j in range(n):
+        if spec.parent[j] == -1:
+            for k in spec.subtree[j]:
+                at += 1
+                slots.root_lo[(j, k)] = -at
+    slots.scratch_words = max(2 * off, at)          # words per lane needed below the exchange region
 
 
 def _chained_costs(spec, cost, post_arith):
@@ -1674,14 +1699,21 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
 
             def where(kind_, j, i):
                 return slots.minv[(j, i)] if kind_ == "M" else scratch(j, 6 if kind_ == "D" else i)
+            partials = tr.mixed and getattr(slots, "partials", None) is not None      # (mixed arithmetic: lean_partial_layout)
+
+            def publish_minv(kind_, j, i, val):
+                tr.xch_put(where(kind_, j, i), val)
+                if partials and kind_ == "M" and (j, i) in slots.root_lo and not isinstance(val.ref, float):
+                    # a base joint's row is final here: its low part too, for the double partial sums of qdd
+                    tr.xch_put(slots.root_lo[(j, i)], val - tr.cast(tr.cast(val, 0), 1))
             if role.minv_bwd:
-                alg.minv_backward_lean(tr, spec, I, Xof_back, lambda kind_, j, i, val: tr.xch_put(where(kind_, j, i), val), role.minv_bwd,
-                                       cols=role.minv_bwd_cols)
+                alg.minv_backward_lean(tr, spec, I, Xof_back, publish_minv, role.minv_bwd, cols=role.minv_bwd_cols)
                 memo.clear()
             if role.c_roots:
                 def publish_c(j, f):
                     c_j = f[spec.S_ind[j]] + qd[j] * spec.damping[j]
-                    tr.xch_put(slots.c[j], (u[j] - c_j) if slots.lean_umc else c_j)
+                    # (mixed arithmetic with double partial sums: c itself; every wave forms u - c in double from its own read of u)
+                    tr.xch_put(slots.c[j], (u[j] - c_j) if (slots.lean_umc and not partials) else c_j)
                 ftab["hook"] = publish_c
                 for root in role.c_roots:
                     facc(root)
@@ -1691,18 +1723,56 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
                 pre_barrier()
             tr.barrier()
             # ---- phase 2: forward pass of the Minv recursion for this wave's columns, then B2
+            final = {}
             if role.minv_cols:
                 def on_final(j, k, val):
                     if slots.minv.get((j, k)) is not None:
                         tr.xch_put(slots.minv[(j, k)], val)
+                        final[(j, k)] = val
                 if getattr(slots, "columns_from_chain", False):      # U, 1/D published only: the whole per-column recursion here
                     alg.minv_columns_lean(tr, spec, Xof_back, lambda kind_, j, i: tr.xch_get(where(kind_, j, i)), role.minv_cols, on_final)
                 else:
                     alg.minv_forward_lean(tr, spec, Xof_back, lambda kind_, j, i: tr.xch_get(where(kind_, j, i)), role.minv_cols, on_final)
                 memo.clear()
-            tr.barrier()
+            if partials:
+                # mixed arithmetic: this wave's share of qdd = Minv_sym (u - c) from the UNROUNDED entries of its columns (double),
+                # B2, published as float pairs where U, 1/D and u - c lived, B2', then every row summed over the waves in double
+                assert slots.lean_umc and getattr(role, "index", None) is not None or not role.minv_cols
+                part, umc = {}, {}
+                with tr.mixed_region():
+                    for k in role.minv_cols:
+                        for j in range(k + 1):
+                            if (j, k) not in slots.minv:
+                                continue
+                            m = final.get((j, k))
+                            if m is None:           # (a base joint's row: final since the backward pass, hi + lo)
+                                m = tr.cast(tr.xch_get(slots.minv[(j, k)]), 1) + tr.xch_get(slots.root_lo[(j, k)])
+                            for (row, col_) in ((j, k), (k, j)) if j != k else ((j, k),):
+                                if col_ not in umc:
+                                    umc[col_] = tr.cast(u[col_], 1) - tr.xch_get(slots.c[col_])
+                                part[row] = tr.fma(m, umc[col_], part[row]) if row in part else m * umc[col_]
+                tr.barrier()
+                if role.minv_cols:
+                    first, rows_w = slots.partials[role.index]
+                    for i_, r in enumerate(rows_w):
+                        p_ = part.get(r, tr.zero())
+                        hi_ = tr.cast(p_, 0)
+                        tr.xch_put(-(1 + 2 * (first + i_)), hi_)
+                        tr.xch_put(-(2 + 2 * (first + i_)), (p_ - tr.cast(hi_, 1)) if not isinstance(p_.ref, float) else tr.zero())
+                tr.barrier()
+                for r in role.qdd_rows:
+                    with tr.mixed_region():
+                        total = None
+                        for w_, (first, rows_w) in sorted(slots.partials.items()):
+                            if r in rows_w:
+                                i_ = rows_w.index(r)
+                                pair = tr.cast(tr.xch_get(-(1 + 2 * (first + i_))), 1) + tr.xch_get(-(2 + 2 * (first + i_)))
+                                total = pair if total is None else total + pair
+                    tr.xch_put(slots.qdd[r], total)
+            else:
+                tr.barrier()
             # ---- phase 3: rows of qdd = Minv_sym (u - c) from the published Minv and c, then B3
-            if role.qdd_rows:
+            if role.qdd_rows and not partials:
                 umc = {}
                 for r in role.qdd_rows:
                     terms = []

@@ -800,7 +800,9 @@ class Tracer:
                 assert len(src) == 1 and (isinstance(src[0], float) or abs(src[0]) < k), "table slot read before it was written"
                 val[k] = rnd(get(src[0]) + np.zeros(1))
             elif op == "in" and a.startswith("in.xch_get("):
-                val[k] = rnd(np.asarray(inputs[a.split("/*")[0]], dtype=np.float64))       # published by another wave's core
+                # published by another wave's core: per slot, or per REQUEST (the full expression with its serial) where the caller
+                # distinguishes what a slot held in the phase of this read from what it holds later (tests/test_lean.py)
+                val[k] = rnd(np.asarray(inputs[a] if a in inputs else inputs[a.split("/*")[0]], dtype=np.float64))
             elif op == "in":
                 val[k] = rnd(np.asarray(inputs[a], dtype=np.float64))
             elif op == "mul":

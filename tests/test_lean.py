@@ -13,7 +13,7 @@ from gridcodegenerator_amd.emit import cores
 from gridcodegenerator_amd.emit.model import RobotSpec
 
 
-def emulate_lean_block(spec, slots, plan, q, qd, u, kind="fd", qdd=None):
+def emulate_lean_block(spec, slots, plan, q, qd, u, kind="fd", qdd=None, dtype="float64"):
     """The block's barriers separate its phases; phase p of every wave reads only what phases < p published.  Sweep p evaluates every
     wave's core against the exchange region as it stands and publishes the `xch` writes of PHASE p only (a Minv slot is written
     twice -- the backward pass's value before B1, the final value between B1 and B2 -- and the forward pass must read the former);
@@ -25,15 +25,30 @@ def emulate_lean_block(spec, slots, plan, q, qd, u, kind="fd", qdd=None):
         base["in.q(%d)" % j] = q[:, j]; base["in.qd(%d)" % j] = qd[:, j]; base["in.u(%d)" % j] = u[:, j]
         if qdd is not None:
             base["in.qdd(%d)" % j] = qdd[:, j]
-    xch = {"in.xch_get(%d)" % s: np.zeros(K) for s in range(-8 * n, slots.count)}      # (negative: the parking words below the region)
+    xch = {"in.xch_get(%d)" % s: np.zeros(K) for s in range(-8 * 34, slots.count)}     # (negative: the parking words below the region)
     got = np.full((K, 2 * n * n), np.nan)
-    phases = (cores.LEAN_BARRIERS if kind == "fd" else 1) + 1
+    phases = [d for (d, _) in traces[0].outputs].count("barrier") + 1       # (4 barriers; 5 in the mixed arithmetic; 1 for the dID block)
+    assert all([d for (d, _) in tr.outputs].count("barrier") == phases - 1 for tr in traces)
+    # every exchange read of a trace with the phase it sits in: in sweep p a read of an EARLIER phase must see what its slot held then
+    # (a Minv slot holds the backward-pass value before B1 and the final value after B2; values computed from the former and
+    # published later -- the double partial sums of qdd in the mixed arithmetic -- would otherwise be recomputed from the latter)
+    reads = []
+    for tr in traces:
+        bars = sorted(pos for (d, _), pos in zip(tr.outputs, tr.out_pos) if d == "barrier")
+        live = tr.live_nodes()
+        reads.append([(tr.nodes[k][1], sum(1 for b in bars if b <= k)) for k in range(1, len(tr.nodes))
+                      if live[k] and tr.nodes[k][0] == "in" and isinstance(tr.nodes[k][1], str) and tr.nodes[k][1].startswith("in.xch_get(")])
+    states = []
     with np.errstate(all="ignore"):
         for sweep in range(phases):
             new = {}
-            for tr in traces:
+            states.append(dict(xch))
+            for tr, rd in zip(traces, reads):
                 inp = dict(base); inp.update(xch)
-                outs = tr.evaluate(inp)
+                for (expr, ph) in rd:
+                    if ph < sweep:
+                        inp[expr] = states[ph][expr.split("/*")[0]]
+                outs = tr.evaluate(inp, dtype=dtype)
                 phase = 0
                 piece = {}
                 for (dst, _), o in zip(tr.outputs, outs):
@@ -57,6 +72,7 @@ def emulate_lean_block(spec, slots, plan, q, qd, u, kind="fd", qdd=None):
                         got[:, tr.run_bases[run] + r] = o
                 assert not piece
             xch.update(new)
+    emulate_lean_block.last_exchange = xch          # (for debugging: the block's LDS after the last phase)
     return got, traces
 
 
@@ -221,6 +237,30 @@ def test_lean_block_with_paired_products_matches_oracle(robots, tables):
     assert not np.isnan(got).any() and relerr(got, ref)[0] < 5e-6
     packed = sum(1 for tr in traces for k, live in enumerate(tr.live_nodes()) if live and k and tr.nodes[k][0] == "pkfma")
     assert packed > 2000
+
+
+def test_lean_block_in_the_mixed_arithmetic(robots, tables, monkeypatch):
+    """Experimental `lean_mixed` (not in the shipped mixed library: profiles/r04/mixed_lean_report.txt): the Minv passes in double
+    inside the waves, floats across LDS, qdd summed in double from per-wave partial sums published as float pairs (one more
+    barrier).  Emulated in float32 storage: clearly better than the fp32 block on the same inputs, five barriers, the partial sums
+    and the base joints' low parts fit the words below the exchange region."""
+    from gridcodegenerator_amd.emit.trace import Tracer
+    from oracle import rbd_oracle as O
+    spec = RobotSpec(robots("atlas30"))
+    n, K = spec.n, 64
+    q, qd, u = (a.astype(np.float64) for a in make_inputs(n, K, 5))
+    ref = O.fd_grad(tables("atlas30"), q, qd, u)
+    ref = np.concatenate([O.flat_colmajor(ref[:, :, :n]), O.flat_colmajor(ref[:, :, n:])], axis=1)
+    err = {}
+    for mixed in (False, True):
+        monkeypatch.setattr(Tracer, "mixed", mixed)
+        slots, plan = cores.lean_plan(spec)
+        got, traces = emulate_lean_block(spec, slots, plan, q, qd, u, dtype="float32")
+        assert not np.isnan(got).any()
+        err[mixed] = relerr(got, ref)[0]
+        assert [d for (d, _) in traces[0].outputs].count("barrier") == (5 if mixed else cores.LEAN_BARRIERS)
+    assert slots.scratch_words <= cores.LEAN_WAVES * 34 and 2 * slots.partial_pairs <= 8 * n
+    assert err[True] < 0.5 * err[False] and err[True] < 2.5e-6, err
 
 
 def test_lean_cores_stay_within_half_a_simd(robots):
