@@ -918,7 +918,14 @@ class AlgorithmEmitMixin:
             if mode == "full":
                 lines.append("gpuErrchk(hipMemcpyAsync(hd_data->d_q_qd_u,hd_data->h_q_qd_u,stride_q_qd_u*num_timesteps*sizeof(T),hipMemcpyHostToDevice,streams[0]));")
             return lines
-        launches = ["forward_dynamics_kernel<T>@L(hd_data->d_qdd,hd_data->d_q_qd_u,stride_q_qd_u,d_robotModel,gravity,num_timesteps);"]
+        launches = [
+            # large robots: the register-lean tile-cooperative kernel where the generator emitted one (FD_LEAN_AUTO_MIN_TILES) -- same
+            # outputs to round-off, blocks/threads then unused
+            "if (false) {}",
+            "else if (FD_LEAN_AUTO_MIN_TILES > 0 && (num_timesteps + GRID_WAVE_SIZE - 1)/GRID_WAVE_SIZE >= FD_LEAN_AUTO_MIN_TILES && "
+            "(FD_LEAN_AUTO_MAX_TILES == 0 || (num_timesteps + GRID_WAVE_SIZE - 1)/GRID_WAVE_SIZE <= FD_LEAN_AUTO_MAX_TILES) && "
+            "forward_dynamics_lean_launch<T>(hd_data->d_qdd,hd_data->d_q_qd_u,stride_q_qd_u,d_robotModel,gravity,num_timesteps,0,@S)) {}",
+            "else {forward_dynamics_kernel<T>@L(hd_data->d_qdd,hd_data->d_q_qd_u,stride_q_qd_u,d_robotModel,gravity,num_timesteps);}"]
         post = ["// finally transfer the result back",
                 "gpuErrchk(hipMemcpy(hd_data->h_qdd,hd_data->d_qdd,NUM_JOINTS*num_timesteps*sizeof(T),hipMemcpyDeviceToHost));",
                 "gpuErrchk(hipDeviceSynchronize());"]
@@ -932,6 +939,7 @@ class AlgorithmEmitMixin:
             self.gen_forward_dynamics_inner(use_thread_group)
         self.gen_forward_dynamics_device(use_thread_group)
         self.gen_forward_dynamics_kernel(use_thread_group)
+        self.gen_forward_dynamics_lean_decl()
         self.gen_forward_dynamics_host()
 
     # ------------------------------------------------------------------------------------------
@@ -2031,6 +2039,148 @@ class AlgorithmEmitMixin:
         self.gen_add_code_line("__host__ inline")
         self.gen_add_code_line("bool forward_dynamics_gradient_lean_attributes(hipFuncAttributes *attr) {", True)
         self.gen_add_code_line("gpuErrchk(hipFuncGetAttributes(attr, reinterpret_cast<const void *>(&forward_dynamics_gradient_kernel_coop8<T>))); return true;")
+        self.gen_add_end_function()
+
+    # ------------------------------------------------------------------------------------------
+    # register-lean tile-cooperative FORWARD DYNAMICS (large robots): the prefix of the gradient kernel as a kernel of its own
+    # ------------------------------------------------------------------------------------------
+    def _lean_fd_prepare(self):
+        """(slots, plan, stage, lds_elems) of `forward_dynamics_kernel_coop8`, or None (fp32, large robots, where the gradient's lean
+        kernel exists: it is that kernel's prefix -- cores.lean_plan_fd)."""
+        if hasattr(self, "_lean_fd_cache"):
+            return self._lean_fd_cache
+        self._lean_fd_cache = None
+        if self.precision != "fp32" or self._lean_prepare() is None:
+            return None
+        W = cores.LEAN_WAVES
+        slots, plan = cores.lean_plan_fd(self.spec, W, **self.lean_plan_options)
+        stage = WAVE * 34
+        self._lean_fd_cache = (slots, plan, stage, W * stage + WAVE * slots.count)
+        return self._lean_fd_cache
+
+    LEAN_FD_LAUNCH_SIG = ("bool forward_dynamics_lean_launch(T *d_qdd, const T *d_q_qd_u, const int stride_q_qd_u, const robotModel<T> *d_robotModel, "
+                          "const T gravity, const int num_timesteps, int tile_blocks, hipStream_t stream)")
+
+    def gen_forward_dynamics_lean_decl(self):
+        """Forward declaration + constants of the register-lean forward-dynamics launcher, ahead of the reference-named host wrapper (a
+        documented block of its own: no other kernel's object-cache key moves)."""
+        prep = self._lean_fd_prepare()
+        W = cores.LEAN_WAVES
+        self.gen_add_func_doc("Launch the register-lean tile-cooperative forward-dynamics kernel (declaration; defined with the kernel at the end of the header)",
+                              ["returns false when this robot / arithmetic has no such kernel (FD_LEAN_WAVES == 0)"], [], None)
+        self.gen_add_code_lines(["template <typename T>", "__host__ inline", self.LEAN_FD_LAUNCH_SIG + ";"])
+        if prep is None:
+            self.gen_add_code_line("const int FD_LEAN_WAVES = 0; // no register-lean forward-dynamics kernel for this robot / arithmetic")
+            self.gen_add_code_line("const int FD_LEAN_AUTO_MIN_TILES = 0;")
+            self.gen_add_code_line("const int FD_LEAN_AUTO_MAX_TILES = 0;")
+            self.gen_add_code_line("const int FD_LEAN_WAVE_MAX_K = 0;")
+        else:
+            slots, plan, stage, lds_elems = prep
+            self.gen_add_code_line("const int FD_LEAN_WAVES = %d; // wavefronts per block of forward_dynamics_kernel_coop8 (block = %d threads, one tile)" % (W, W * WAVE))
+            self.gen_add_code_line("const int FD_LEAN_AUTO_MIN_TILES = %d; // automatic choice of that kernel from this many tiles on (0: only on request)" % self.lean_fd_auto_min_tiles)
+            # Atlas-30 (profiles/r04/lean_fd_sweep.txt): 12.4-13.0 us up to one tile per CU against 28 us for the lane-per-configuration
+            # kernel (one wave per CU there); beyond two tiles per CU that kernel has a wave on every SIMD and wins (K = 65536: 37 against 49 us)
+            self.gen_add_code_line("const int FD_LEAN_AUTO_MAX_TILES = %d; // ... and up to this many tiles (0: no upper limit)" % self.lean_fd_auto_max_tiles)
+            self.gen_add_code_line("const int FD_LEAN_SHARED_MEM_COUNT = %d; // dynamic LDS in T elements: %d staging regions of %d + %d exchange slots x 64 lanes"
+                                   % (lds_elems, W, stage, slots.count))
+            self.gen_add_code_line("const int FD_LEAN_WAVE_MAX_K = %d; // the wave-per-configuration kernel automatically only up to this batch size (0: FD_WAVE_AUTO_MAX_K alone decides)" % self.lean_fd_wave_max_k)
+        self.gen_add_code_line("")
+
+    def gen_forward_dynamics_lean(self, use_thread_group=False):
+        """`forward_dynamics_kernel_coop8`: qdd = Minv (u - c) of a large robot on the register-lean block of the gradient kernel -- its
+        prefix as a kernel of its own (input table; Minv recursion once per base-rooted tree, shared through LDS, forward pass over all
+        eight waves; bias torques depth first; qdd rows), then one wave writes the n accelerations.  The lane-per-configuration kernel
+        runs the whole chain of a configuration on one lane: one wave per CU at K = 16384 for Atlas-30.  Reference mapping being
+        replaced: algorithms/_forward_dynamics.py:21-112 (block per configuration)."""
+        n, W = self.spec.n, cores.LEAN_WAVES
+        prep = self._lean_fd_prepare()
+        if prep is None:
+            self.gen_add_func_doc("No register-lean forward-dynamics kernel for this robot / arithmetic", [], [], None)
+            self.gen_add_code_lines(["template <typename T>", "__host__ inline",
+                                     "bool forward_dynamics_lean_launch(T *, const T *, const int, const robotModel<T> *, const T, const int, int, hipStream_t) {return false;}",
+                                     "template <typename T>", "__host__ inline",
+                                     "bool forward_dynamics_lean_attributes(hipFuncAttributes *) {return false;}", ""])
+            return
+        slots, plan, stage, lds_elems = prep
+        xch_off = W * stage
+        names = []
+        for w, (role, items) in enumerate(plan):
+            cname = "forward_dynamics_lean_core_w%d" % w
+            tr = cores.core_gradient_recompute(self.spec, "fd", cols=items, coop=(role, slots))
+            self._emit_core(cname, "Register-lean tile-cooperative forward dynamics, wave %d of %d: %r%s" % (w, W, role, "; writes qdd" if role.out_qdd else ""),
+                            tr, order="creation")
+            names.append((cname, role.out_qdd))
+        self.kernel_instances.append("__global__ void @NS::forward_dynamics_kernel_coop8<T>(T *, const T *, const int, "
+                                     "const @NS::robotModel<T> *, const T, const int);")
+        self.gen_add_func_doc("Computes forward dynamics (register-lean tile-cooperative: %d wavefronts, two per SIMD, share each tile of 64 configurations)" % W,
+                              ["launch with EXACTLY %d threads per block and FD_LEAN_SHARED_MEM_COUNT*sizeof(T) of dynamic LDS" % (W * WAVE),
+                               "(use forward_dynamics_lean_launch); blocks grid-stride over the tiles"],
+                              ["d_qdd is the output buffer, %d values per configuration" % n,
+                               "d_q_qd_u is the input buffer, %d values read per configuration" % (3 * n),
+                               "stride_q_qd_u is the stride between configurations in d_q_qd_u",
+                               "d_robotModel is the pointer to the initialized model specific helpers on the GPU (unused: constants are baked in)",
+                               "gravity is the gravity constant", "NUM_TIMESTEPS is the number of configurations"], None)
+        self.gen_add_code_line("template <typename T, typename C = typename grid_compute<T>::type>")
+        self.gen_add_code_line("__global__ __launch_bounds__(%d)" % (W * WAVE))
+        self.gen_add_code_line("void forward_dynamics_kernel_coop8(T *d_qdd, const T *d_q_qd_u, const int stride_q_qd_u, "
+                               "const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS) {", True)
+        self.gen_add_code_lines([
+            "extern __shared__ __align__(16) unsigned char s_grid_dyn[];",
+            "grid_tile_iter it(NUM_TIMESTEPS);              // lane / wave bookkeeping only: the tile loop below is per BLOCK",
+            "T *s_wave = reinterpret_cast<T *>(s_grid_dyn) + it.wave_in_block*%d;" % stage,
+            "T *s_xch = reinterpret_cast<T *>(s_grid_dyn) + %d;" % xch_off,
+            "const int nblocks = grid_num_blocks();",
+            "const int bid = grid_block_id();",
+            "if (grid_block_threads() != %d){return;}    // (the launcher guarantees it; a wrong shape must not deadlock the barriers)" % (W * WAVE),
+            "for (int k0 = bid*GRID_WAVE_SIZE; k0 < NUM_TIMESTEPS; k0 += nblocks*GRID_WAVE_SIZE){",
+        ])
+        self.indent_level += 1
+        self.gen_add_code_line("const T *s_q_qd_u = grid_opaque_uniform(d_q_qd_u + (size_t)k0*stride_q_qd_u);")
+        self.gen_add_code_line("const unsigned in_row = (unsigned)min(it.lane, NUM_TIMESTEPS - 1 - k0)*(unsigned)stride_q_qd_u*(unsigned)sizeof(T);")
+        self.gen_add_code_line("const unsigned xb = (unsigned)reinterpret_cast<unsigned long long>(s_xch) + (unsigned)sizeof(T)*it.lane;")
+        self.gen_add_code_line("const grid_in_lean<T> in = {s_q_qd_u, s_q_qd_u + %d, s_q_qd_u + %d, s_xch, it.lane, xb, xb + 256u*GRID_WAVE_SIZE*(unsigned)sizeof(T), "
+                               "xb - 256u*GRID_WAVE_SIZE*(unsigned)sizeof(T), in_row};" % (n, 2 * n))
+        self.gen_add_code_line("switch (it.wave_in_block){", True)
+        for w, (cname, writes) in enumerate(names):
+            self.gen_add_code_line("case %d: {" % w, True)
+            if writes:
+                self.gen_add_code_line("grid_out_pieces<T,%d> out = {s_wave, d_qdd, k0, it.lane, it.W, NUM_TIMESTEPS};" % n)
+            else:
+                self.gen_add_code_line("grid_out_ptr<T> out = {nullptr};     // (this core stores nothing)")
+            self.gen_add_code_line("%s<T,C>(in, out, gravity);" % cname)
+            self.gen_add_code_line("break;")
+            self.gen_add_end_control_flow()
+        self.gen_add_code_line("default: break;")
+        self.gen_add_end_control_flow()
+        self.gen_add_code_line("grid_block_sync();     // the exchange region and the staging regions are rewritten by the next tile")
+        self.gen_add_end_control_flow()
+        self.gen_add_end_function()
+        self.gen_add_func_doc("Launch the register-lean tile-cooperative forward-dynamics kernel (asynchronous, on `stream`)",
+                              ["tile_blocks <= 0: one block per tile of 64 configurations (capped at 4*SUGGESTED_MAX_BLOCKS)"], [], None)
+        self.gen_add_code_line("template <typename T>")
+        self.gen_add_code_line("__host__ inline")
+        self.gen_add_code_line(self.LEAN_FD_LAUNCH_SIG + " {", True)
+        self.gen_add_code_lines([
+            "const size_t lds_bytes = (size_t)FD_LEAN_SHARED_MEM_COUNT*sizeof(T);",
+            "static thread_local int configured_device = -1;        // > 64 KiB of dynamic LDS must be enabled once per device",
+            "int dev = 0; gpuErrchk(hipGetDevice(&dev));",
+            "if (lds_bytes > 65536 && configured_device != dev){",
+            "    gpuErrchk(hipFuncSetAttribute(reinterpret_cast<const void *>(&forward_dynamics_kernel_coop8<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));",
+            "    configured_device = dev;",
+            "}",
+            "const int tiles = (num_timesteps + GRID_WAVE_SIZE - 1)/GRID_WAVE_SIZE;",
+            "if (tile_blocks <= 0 || tile_blocks > tiles){tile_blocks = tiles;}",
+            "if (tile_blocks > 4*SUGGESTED_MAX_BLOCKS){tile_blocks = 4*SUGGESTED_MAX_BLOCKS;}",
+            "forward_dynamics_kernel_coop8<T><<<dim3(tile_blocks,1,1),dim3(%d,1,1),lds_bytes,stream>>>(d_qdd,d_q_qd_u,stride_q_qd_u,d_robotModel,gravity,num_timesteps);" % (W * WAVE),
+            "gpuErrchk(hipGetLastError());",
+            "return true;",
+        ])
+        self.gen_add_end_function()
+        self.gen_add_func_doc("hipFuncGetAttributes of the register-lean forward-dynamics kernel", ["returns false when this robot has none"], [], None)
+        self.gen_add_code_line("template <typename T>")
+        self.gen_add_code_line("__host__ inline")
+        self.gen_add_code_line("bool forward_dynamics_lean_attributes(hipFuncAttributes *attr) {", True)
+        self.gen_add_code_line("gpuErrchk(hipFuncGetAttributes(attr, reinterpret_cast<const void *>(&forward_dynamics_kernel_coop8<T>))); return true;")
         self.gen_add_end_function()
 
     # ------------------------------------------------------------------------------------------

@@ -321,6 +321,8 @@ class LeanRole:
         qdd_rows    phase 3: rows r of qdd = Minv_sym (u - c) this wave computes from the published Minv and c        -> barrier B3
     Every wave executes the same four barriers."""
 
+    out_qdd = False         # (forward-dynamics kernel on the same block, lean_plan_fd: this wave writes qdd to the output after B3)
+
     def __init__(self, name="consumer", joints=(), minv_bwd=(), minv_cols=(), c_roots=(), hoist=(), qdd_rows=(), minv_bwd_cols=None):
         self.name, self.joints, self.minv_bwd, self.minv_cols = name, list(joints), list(minv_bwd), sorted(minv_cols)
         self.minv_bwd_cols = None if minv_bwd_cols is None else sorted(minv_bwd_cols)     # (only these columns of the backward pass)
@@ -532,6 +534,20 @@ def _chained_costs(spec, cost, post_arith):
             top_extra[c_] = max(0.0, cost[(c_, 0)] - behind)
             cost[(c_, 0)] = min(cost[(c_, 0)], behind)
     return top_extra
+
+
+def lean_plan_fd(spec, waves=LEAN_WAVES, **options):
+    """The register-lean block as a FORWARD-DYNAMICS kernel (qdd = Minv (u - c) only): the prefix of lean_plan -- input table, Minv
+    recursion shared through LDS, bias torques, qdd rows -- without gradient columns and without parked recursions; wave 0 writes
+    the n accelerations of the tile's configurations after B3.  Same arithmetic as the prefix of the gradient kernel (and, to three
+    digits, the accuracy of the lane-per-configuration forward-dynamics core)."""
+    slots, plan = lean_plan(spec, waves, **options)
+    out = []
+    for w, (role, _) in enumerate(plan):
+        role.hoist = []
+        role.out_qdd = (w == 0)
+        out.append((role, []))
+    return slots, out
 
 
 def lean_plan_id(spec, use_qdd=False, waves=LEAN_WAVES, chain_f=False):
@@ -1788,6 +1804,15 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
                     tr.xch_put(slots.qdd[r], row)
             tr.barrier()
             qdd = [tr.zero()] * n       # (placeholders: touch() reads the published qdd of every joint it visits)
+            if getattr(role, "out_qdd", False):
+                # forward-dynamics kernel (lean_plan_fd): the block's result is qdd itself -- this wave writes the n values per
+                # configuration (row length n), in pieces of at most 32
+                vals = [tr.xch_get(slots.qdd[r]) for r in range(n)]
+                for at in range(0, n, AlignedPieces.MAX_PIECE):
+                    chunk = vals[at:at + AlignedPieces.MAX_PIECE]
+                    for pos, v_ in enumerate(chunk):
+                        tr.out("piece:%d:%d" % (len(chunk), pos), v_)
+                    tr.out("flush:%d:%d" % (len(chunk), at), 0.0)
         else:
             X = alg.build_X(tr, spec, q, trig)
             qdd = list(_coop_prologue(tr, spec, slots, role, X, I, list(qd), u, g, demand_order=False, pre_barrier=pre_barrier if hoist else None))

@@ -120,7 +120,10 @@ int grid_get_split(grid_handle *h, int alg, int num_timesteps);
  * The same block serves the INVERSE-dynamics gradient at qdd = 0 (`inverse_dynamics_gradient_kernel_coop8`, alg = GRID_ALG_ID_DU:
  * input table, one barrier, gradient half-columns; replaces algorithms/_inverse_dynamics_gradient.py:199-246,501-540's
  * block-per-configuration mapping for large robots): grid_lean_available(GRID_ALG_ID_DU), grid_set_coop(h, GRID_ALG_ID_DU, 0|1|3),
- * automatic from ID_DU_LEAN_AUTO_MIN_TILES on; a call with d_qdd != NULL keeps the lane-per-configuration kernel. */
+ * automatic from ID_DU_LEAN_AUTO_MIN_TILES on; a call with d_qdd != NULL keeps the lane-per-configuration kernel.
+ * And FORWARD DYNAMICS itself (`forward_dynamics_kernel_coop8`, alg = GRID_ALG_FD: the gradient kernel's prefix -- input table, shared
+ * Minv recursion, bias torques, qdd rows -- then one wave writes qdd; replaces algorithms/_forward_dynamics.py:21-112's block per
+ * configuration for large robots): grid_lean_available(GRID_ALG_FD), grid_set_coop(h, GRID_ALG_FD, 0|1|3), FD_LEAN_AUTO_MIN_TILES. */
 int grid_coop_available(int alg);
 int grid_lean_available(int alg);
 int grid_set_coop(grid_handle *h, int alg, int mode);

@@ -263,6 +263,24 @@ def test_lean_block_in_the_mixed_arithmetic(robots, tables, monkeypatch):
     assert err[True] < 0.5 * err[False] and err[True] < 2.5e-6, err
 
 
+def test_lean_forward_dynamics_block_matches_oracle(robots, tables):
+    """cores.lean_plan_fd: the register-lean block as a forward-dynamics kernel -- the gradient kernel's prefix, no gradient columns, no
+    parked recursions, wave 0 writes the n accelerations in one piece after B3."""
+    from oracle import rbd_oracle as O
+    spec = RobotSpec(robots("atlas30"))
+    n, K = spec.n, 3
+    q, qd, u = (a.astype(np.float64) for a in make_inputs(n, K, 68))
+    parts = O.fd_grad(tables("atlas30"), q, qd, u, return_parts=True)[1]
+    slots, plan = cores.lean_plan_fd(spec)
+    assert [role.out_qdd for (role, _) in plan] == [True] + [False] * 7 and all(not items and not role.hoist for (role, items) in plan)
+    traces = [cores.core_gradient_recompute(spec, "fd", cols=items, coop=(role, slots)) for (role, items) in plan]
+    got, _ = emulate_lean_block(spec, slots, plan, q, qd, u)
+    assert not np.isnan(got[:, :n]).any() and np.isnan(got[:, n:]).all()         # exactly the n accelerations are written (row offsets 0 .. n-1)
+    assert relerr(got[:, :n], parts["qdd"])[0] < 1e-6
+    total = sum(cores.lean_arith(tr) for tr in traces)
+    assert total < 20000, total                # (a quarter of the gradient kernel's tile: 15.7 k instructions for Atlas-30)
+
+
 def test_lean_cores_stay_within_half_a_simd(robots):
     """The point of the exercise: the values a lean core holds at once (creation-order emission, the order the kernel is emitted in)
     stay far below 256 -- the 4-wave cores of the same robot hold 280-390 in their prologue alone -- and the block's LDS fits the CU."""
@@ -465,3 +483,43 @@ def test_mixed_library_has_the_lean_inverse_dynamics_gradient_only(tables):
             outs.append(o.cpu().numpy())
         assert np.array_equal(outs[0], outs[1])
         assert relerr(outs[0], oracle_all(T, q, qd, u)["dc_du_noqdd"])[0] < TOL_BY_PRECISION["mixed"]["atlas30"]["dc_du"]
+
+
+@pytest.mark.gpu
+def test_lean_forward_dynamics_kernel_on_gpu(tables):
+    """`forward_dynamics_kernel_coop8` through the C ABI: automatic for Atlas-30 above the wave-per-configuration kernel's batch sizes
+    (grid_get_coop = 2), qdd within the north star's 1e-6 of the oracle and to round-off of the lane-per-configuration kernel, ragged
+    batches, few blocks, rows past the batch untouched, no scratch."""
+    import torch
+    from gridcodegenerator_amd import host
+    from test_gpu_parity import NORTH_STAR, TOL, oracle_all, pack
+    robot, alg = "atlas30", host.ALG_FD
+    T = tables(robot)
+    with host.GridHandle(robot, device=0, precision=host.DEFAULT_PRECISION) as h:
+        assert h.lean_available(alg)
+        attrs = h.L.kernel_attributes(alg, coop=2)
+        assert attrs["numRegs"] <= 256 and attrs["scratch_bytes_per_lane"] == 0, attrs
+        n = h.n
+        assert h.get_wave(alg, 64) and h.get_coop(alg, 4096) == 2          # small batches keep the wave-per-configuration kernel
+        assert h.get_coop(alg, 32768) == 2 and h.get_coop(alg, 65536) == 0 and not h.get_wave(alg, 1024)    # ... large ones the lane kernel
+        for K in (1, 70, 333, 1500):
+            q, qd, u = make_inputs(n, K, 290 + K)
+            ref = oracle_all(T, q, qd, u)["qdd"]
+            d_in = torch.from_numpy(pack(q, qd, u)).cuda()
+            h.set_coop(alg, 1); h.set_wave(alg, 1)
+            lanes = torch.zeros((K, n), dtype=torch.float32, device="cuda")
+            h.forward_dynamics_device(lanes.data_ptr(), d_in.data_ptr(), 3 * n, K); h.synchronize()
+            h.set_coop(alg, 3)
+            outs = []
+            for blocks in (0, 1, 2):
+                out = torch.full((K + 2, n), 4.25, dtype=torch.float32, device="cuda")
+                h.forward_dynamics_device(out.data_ptr(), d_in.data_ptr(), 3 * n, K, blocks=blocks); h.synchronize()
+                o = out.cpu().numpy()
+                assert np.all(o[K:] == 4.25)
+                outs.append(o[:K])
+            assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+            err = relerr(outs[0], ref)[0]
+            print("lean FD kernel K=%d: qdd error %.2e (lane-per-configuration kernel %.2e)" % (K, err, relerr(lanes.cpu().numpy(), ref)[0]))
+            assert err < min(TOL[robot]["qdd"], NORTH_STAR), (K, err)
+            assert relerr(outs[0], lanes.cpu().numpy().astype(np.float64))[0] < 2 * TOL[robot]["qdd"]
+        h.set_coop(alg, 0); h.set_wave(alg, 0)
