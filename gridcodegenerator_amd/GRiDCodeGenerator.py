@@ -167,6 +167,7 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, SpatialAlgebraEmitMixin, Al
         self.in_rows = bool(exp["in_rows"])
         self.split_half_columns = bool(exp["split_half_columns"])
         self.lean_wave_max_k, self.lean_id_wave_max_k = 768, 1408     # batch sizes from which the lean kernels beat the wave-per-configuration kernels
+        self.lean_minv_auto = (1, 256, 1152)      # (profiles/r04/lean_minv_sweep.txt)      # register-lean direct-Minv kernel: automatic from / up to this many tiles; wave-per-configuration kernel up to this batch size
         self.lean_fd_auto_min_tiles, self.lean_fd_auto_max_tiles, self.lean_fd_wave_max_k = 1, 512, 640      # register-lean forward-dynamics kernel (profiles/r04/lean_fd_sweep.txt)
         self.lean_id_auto_min_tiles = 1    # register-lean inverse-dynamics-gradient kernel: automatic from this many tiles on
         self.lean_auto_min_tiles = 1       # register-lean 8-wave kernel: automatic from this many tiles on (0: on request) -- measured faster than
@@ -347,6 +348,7 @@ class GRiDCodeGenerator(TextMixin, RuntimeEmitMixin, SpatialAlgebraEmitMixin, Al
         self.gen_forward_dynamics_gradient_lean(use_thread_group)       # (after everything else: no earlier kernel's object-cache key moves)
         self.gen_inverse_dynamics_gradient_lean(use_thread_group)
         self.gen_forward_dynamics_lean(use_thread_group)
+        self.gen_direct_minv_lean(use_thread_group)
         self.gen_init_close_grid()
         self.gen_add_end_control_flow()
         self.gen_kernel_instance_list()

@@ -856,7 +856,12 @@ class AlgorithmEmitMixin:
                         "if (USE_COMPRESSED_MEM) {stride_q = NUM_JOINTS; gpuErrchk(hipMemcpyAsync(hd_data->d_q,hd_data->h_q,stride_q*num_timesteps*sizeof(T),hipMemcpyHostToDevice,streams[0]));}",
                         "else {stride_q = 3*NUM_JOINTS; gpuErrchk(hipMemcpyAsync(hd_data->d_q_qd_u,hd_data->h_q_qd_u,stride_q*num_timesteps*sizeof(T),hipMemcpyHostToDevice,streams[0]));}"]
             return ["const int stride_q = USE_COMPRESSED_MEM ? NUM_JOINTS: 3*NUM_JOINTS;"]
-        launches = ["direct_minv_kernel<T>@L(hd_data->d_Minv,USE_COMPRESSED_MEM ? hd_data->d_q : hd_data->d_q_qd_u,stride_q,d_robotModel,num_timesteps);"]
+        launches = [
+            "if (false) {}",
+            "else if (MINV_LEAN_AUTO_MIN_TILES > 0 && (num_timesteps + GRID_WAVE_SIZE - 1)/GRID_WAVE_SIZE >= MINV_LEAN_AUTO_MIN_TILES && "
+            "(MINV_LEAN_AUTO_MAX_TILES == 0 || (num_timesteps + GRID_WAVE_SIZE - 1)/GRID_WAVE_SIZE <= MINV_LEAN_AUTO_MAX_TILES) && "
+            "direct_minv_lean_launch<T>(hd_data->d_Minv,USE_COMPRESSED_MEM ? hd_data->d_q : hd_data->d_q_qd_u,stride_q,d_robotModel,num_timesteps,0,@S)) {}",
+            "else {direct_minv_kernel<T>@L(hd_data->d_Minv,USE_COMPRESSED_MEM ? hd_data->d_q : hd_data->d_q_qd_u,stride_q,d_robotModel,num_timesteps);}"]
         post = ["// finally transfer the result back",
                 "gpuErrchk(hipMemcpy(hd_data->h_Minv,hd_data->d_Minv,NUM_JOINTS*NUM_JOINTS*num_timesteps*sizeof(T),hipMemcpyDeviceToHost));",
                 "gpuErrchk(hipDeviceSynchronize());"]
@@ -870,6 +875,7 @@ class AlgorithmEmitMixin:
             self.gen_direct_minv_inner(use_thread_group)
         self.gen_direct_minv_device(use_thread_group)
         self.gen_direct_minv_kernel(use_thread_group)
+        self.gen_direct_minv_lean_decl()
         self.gen_direct_minv_host()
 
     # ------------------------------------------------------------------------------------------
@@ -2181,6 +2187,137 @@ class AlgorithmEmitMixin:
         self.gen_add_code_line("__host__ inline")
         self.gen_add_code_line("bool forward_dynamics_lean_attributes(hipFuncAttributes *attr) {", True)
         self.gen_add_code_line("gpuErrchk(hipFuncGetAttributes(attr, reinterpret_cast<const void *>(&forward_dynamics_kernel_coop8<T>))); return true;")
+        self.gen_add_end_function()
+
+    # ------------------------------------------------------------------------------------------
+    # register-lean tile-cooperative DIRECT Minv (large robots): phases 0-2 of the gradient kernel, columns written from registers
+    # ------------------------------------------------------------------------------------------
+    def _lean_minv_prepare(self):
+        if hasattr(self, "_lean_minv_cache"):
+            return self._lean_minv_cache
+        self._lean_minv_cache = None
+        if self.precision != "fp32" or self._lean_prepare() is None:
+            return None
+        W = cores.LEAN_WAVES
+        slots, plan = cores.lean_plan_minv(self.spec, W, **self.lean_plan_options)
+        stage = WAVE * 34
+        self._lean_minv_cache = (slots, plan, stage, W * stage + WAVE * slots.count)
+        return self._lean_minv_cache
+
+    LEAN_MINV_LAUNCH_SIG = ("bool direct_minv_lean_launch(T *d_Minv, const T *d_q, const int stride_q, const robotModel<T> *d_robotModel, "
+                            "const int num_timesteps, int tile_blocks, hipStream_t stream)")
+
+    def gen_direct_minv_lean_decl(self):
+        """Forward declaration + constants of the register-lean direct-Minv launcher, ahead of the reference-named host wrapper."""
+        prep = self._lean_minv_prepare()
+        W = cores.LEAN_WAVES
+        self.gen_add_func_doc("Launch the register-lean tile-cooperative direct-Minv kernel (declaration; defined with the kernel at the end of the header)",
+                              ["returns false when this robot / arithmetic has no such kernel (MINV_LEAN_WAVES == 0)"], [], None)
+        self.gen_add_code_lines(["template <typename T>", "__host__ inline", self.LEAN_MINV_LAUNCH_SIG + ";"])
+        if prep is None:
+            self.gen_add_code_lines(["const int MINV_LEAN_WAVES = 0; // no register-lean direct-Minv kernel for this robot / arithmetic",
+                                     "const int MINV_LEAN_AUTO_MIN_TILES = 0;", "const int MINV_LEAN_AUTO_MAX_TILES = 0;", "const int MINV_LEAN_WAVE_MAX_K = 0;"])
+        else:
+            slots, plan, stage, lds_elems = prep
+            self.gen_add_code_line("const int MINV_LEAN_WAVES = %d; // wavefronts per block of direct_minv_kernel_coop8 (block = %d threads, one tile)" % (W, W * WAVE))
+            self.gen_add_code_line("const int MINV_LEAN_AUTO_MIN_TILES = %d; // automatic choice of that kernel from this many tiles on (0: only on request)" % self.lean_minv_auto[0])
+            self.gen_add_code_line("const int MINV_LEAN_AUTO_MAX_TILES = %d; // ... and up to this many tiles (0: no upper limit)" % self.lean_minv_auto[1])
+            self.gen_add_code_line("const int MINV_LEAN_SHARED_MEM_COUNT = %d; // dynamic LDS in T elements: %d staging regions of %d + %d exchange slots x 64 lanes"
+                                   % (lds_elems, W, stage, slots.count))
+            self.gen_add_code_line("const int MINV_LEAN_WAVE_MAX_K = %d; // the wave-per-configuration kernel automatically only up to this batch size (0: MINV_WAVE_AUTO_MAX_K alone decides)" % self.lean_minv_auto[2])
+        self.gen_add_code_line("")
+
+    def gen_direct_minv_lean(self, use_thread_group=False):
+        """`direct_minv_kernel_coop8`: Minv (upper triangle) of a large robot on the register-lean block -- input table (sin q, cos q), the
+        backward pass of the recursion once per base-rooted tree, the forward pass over all eight waves, every wave writing the columns it
+        finishes from registers.  Reads q only (stride_q may be NUM_JOINTS).  Reference mapping being replaced: algorithms/_direct_minv.py:
+        23-382 (block per configuration)."""
+        n, W = self.spec.n, cores.LEAN_WAVES
+        prep = self._lean_minv_prepare()
+        if prep is None:
+            self.gen_add_func_doc("No register-lean direct-Minv kernel for this robot / arithmetic", [], [], None)
+            self.gen_add_code_lines(["template <typename T>", "__host__ inline",
+                                     "bool direct_minv_lean_launch(T *, const T *, const int, const robotModel<T> *, const int, int, hipStream_t) {return false;}",
+                                     "template <typename T>", "__host__ inline",
+                                     "bool direct_minv_lean_attributes(hipFuncAttributes *) {return false;}", ""])
+            return
+        slots, plan, stage, lds_elems = prep
+        xch_off = W * stage
+        names = []
+        for w, (role, items) in enumerate(plan):
+            cname = "direct_minv_lean_core_w%d" % w
+            tr = cores.core_gradient_recompute(self.spec, "fd", cols=items, coop=(role, slots))
+            self._emit_core(cname, "Register-lean tile-cooperative direct Minv, wave %d of %d: %r; writes columns %s" % (w, W, role, role.minv_cols), tr, order="creation")
+            names.append((cname, bool(role.minv_cols)))
+        self.kernel_instances.append("__global__ void @NS::direct_minv_kernel_coop8<T>(T *, const T *, const int, const @NS::robotModel<T> *, const int);")
+        self.gen_add_func_doc("Compute the inverse of the mass matrix (register-lean tile-cooperative: %d wavefronts, two per SIMD, share each tile of 64 configurations)" % W,
+                              ["launch with EXACTLY %d threads per block and MINV_LEAN_SHARED_MEM_COUNT*sizeof(T) of dynamic LDS" % (W * WAVE),
+                               "(use direct_minv_lean_launch); blocks grid-stride over the tiles"],
+                              ["d_Minv is the output buffer, %d values per configuration (column-major, upper triangle)" % (n * n),
+                               "d_q is the input buffer, %d values read per configuration" % n,
+                               "stride_q is the stride between configurations in d_q",
+                               "d_robotModel is the pointer to the initialized model specific helpers on the GPU (unused: constants are baked in)",
+                               "NUM_TIMESTEPS is the number of configurations"], None)
+        self.gen_add_code_line("template <typename T, typename C = typename grid_compute<T>::type>")
+        self.gen_add_code_line("__global__ __launch_bounds__(%d)" % (W * WAVE))
+        self.gen_add_code_line("void direct_minv_kernel_coop8(T *d_Minv, const T *d_q, const int stride_q, const robotModel<T> *d_robotModel, const int NUM_TIMESTEPS) {", True)
+        self.gen_add_code_lines([
+            "extern __shared__ __align__(16) unsigned char s_grid_dyn[];",
+            "grid_tile_iter it(NUM_TIMESTEPS);              // lane / wave bookkeeping only: the tile loop below is per BLOCK",
+            "T *s_wave = reinterpret_cast<T *>(s_grid_dyn) + it.wave_in_block*%d;" % stage,
+            "T *s_xch = reinterpret_cast<T *>(s_grid_dyn) + %d;" % xch_off,
+            "const int nblocks = grid_num_blocks();",
+            "const int bid = grid_block_id();",
+            "if (grid_block_threads() != %d){return;}    // (the launcher guarantees it; a wrong shape must not deadlock the barriers)" % (W * WAVE),
+            "for (int k0 = bid*GRID_WAVE_SIZE; k0 < NUM_TIMESTEPS; k0 += nblocks*GRID_WAVE_SIZE){",
+        ])
+        self.indent_level += 1
+        self.gen_add_code_line("const T *s_q = grid_opaque_uniform(d_q + (size_t)k0*stride_q);       // (q only: the cores of this kernel read nothing else)")
+        self.gen_add_code_line("const unsigned in_row = (unsigned)min(it.lane, NUM_TIMESTEPS - 1 - k0)*(unsigned)stride_q*(unsigned)sizeof(T);")
+        self.gen_add_code_line("const unsigned xb = (unsigned)reinterpret_cast<unsigned long long>(s_xch) + (unsigned)sizeof(T)*it.lane;")
+        self.gen_add_code_line("const grid_in_lean<T> in = {s_q, nullptr, nullptr, s_xch, it.lane, xb, xb + 256u*GRID_WAVE_SIZE*(unsigned)sizeof(T), "
+                               "xb - 256u*GRID_WAVE_SIZE*(unsigned)sizeof(T), in_row};")
+        self.gen_add_code_line("switch (it.wave_in_block){", True)
+        for w, (cname, writes) in enumerate(names):
+            self.gen_add_code_line("case %d: {" % w, True)
+            if writes:
+                self.gen_add_code_line("grid_out_pieces<T,%d> out = {s_wave, d_Minv, k0, it.lane, it.W, NUM_TIMESTEPS};" % (n * n))
+            else:
+                self.gen_add_code_line("grid_out_ptr<T> out = {nullptr};     // (this core stores nothing)")
+            self.gen_add_code_line("%s<T,C>(in, out, static_cast<T>(0));" % cname)
+            self.gen_add_code_line("break;")
+            self.gen_add_end_control_flow()
+        self.gen_add_code_line("default: break;")
+        self.gen_add_end_control_flow()
+        self.gen_add_code_line("grid_block_sync();     // the exchange region and the staging regions are rewritten by the next tile")
+        self.gen_add_end_control_flow()
+        self.gen_add_end_function()
+        self.gen_add_func_doc("Launch the register-lean tile-cooperative direct-Minv kernel (asynchronous, on `stream`)",
+                              ["tile_blocks <= 0: one block per tile of 64 configurations (capped at 4*SUGGESTED_MAX_BLOCKS)"], [], None)
+        self.gen_add_code_line("template <typename T>")
+        self.gen_add_code_line("__host__ inline")
+        self.gen_add_code_line(self.LEAN_MINV_LAUNCH_SIG + " {", True)
+        self.gen_add_code_lines([
+            "const size_t lds_bytes = (size_t)MINV_LEAN_SHARED_MEM_COUNT*sizeof(T);",
+            "static thread_local int configured_device = -1;        // > 64 KiB of dynamic LDS must be enabled once per device",
+            "int dev = 0; gpuErrchk(hipGetDevice(&dev));",
+            "if (lds_bytes > 65536 && configured_device != dev){",
+            "    gpuErrchk(hipFuncSetAttribute(reinterpret_cast<const void *>(&direct_minv_kernel_coop8<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));",
+            "    configured_device = dev;",
+            "}",
+            "const int tiles = (num_timesteps + GRID_WAVE_SIZE - 1)/GRID_WAVE_SIZE;",
+            "if (tile_blocks <= 0 || tile_blocks > tiles){tile_blocks = tiles;}",
+            "if (tile_blocks > 4*SUGGESTED_MAX_BLOCKS){tile_blocks = 4*SUGGESTED_MAX_BLOCKS;}",
+            "direct_minv_kernel_coop8<T><<<dim3(tile_blocks,1,1),dim3(%d,1,1),lds_bytes,stream>>>(d_Minv,d_q,stride_q,d_robotModel,num_timesteps);" % (W * WAVE),
+            "gpuErrchk(hipGetLastError());",
+            "return true;",
+        ])
+        self.gen_add_end_function()
+        self.gen_add_func_doc("hipFuncGetAttributes of the register-lean direct-Minv kernel", ["returns false when this robot has none"], [], None)
+        self.gen_add_code_line("template <typename T>")
+        self.gen_add_code_line("__host__ inline")
+        self.gen_add_code_line("bool direct_minv_lean_attributes(hipFuncAttributes *attr) {", True)
+        self.gen_add_code_line("gpuErrchk(hipFuncGetAttributes(attr, reinterpret_cast<const void *>(&direct_minv_kernel_coop8<T>))); return true;")
         self.gen_add_end_function()
 
     # ------------------------------------------------------------------------------------------

@@ -246,10 +246,12 @@ static int effective_split(const grid_handle *h, int alg, int K) {
 // chips only in the mixed arithmetic, small robots only on request.
 static bool coop_available(int alg) { return alg == GRID_ALG_FD_DU && G::FD_DU_COOP_WAVES > 0; }
 static bool lean_available(int alg) {
-    return (alg == GRID_ALG_FD_DU && G::FD_DU_LEAN_WAVES > 0) || (alg == GRID_ALG_ID_DU && G::ID_DU_LEAN_WAVES > 0) || (alg == GRID_ALG_FD && G::FD_LEAN_WAVES > 0);
+    return (alg == GRID_ALG_FD_DU && G::FD_DU_LEAN_WAVES > 0) || (alg == GRID_ALG_ID_DU && G::ID_DU_LEAN_WAVES > 0) || (alg == GRID_ALG_FD && G::FD_LEAN_WAVES > 0)
+        || (alg == GRID_ALG_MINV && G::MINV_LEAN_WAVES > 0);
 }
 static int lean_auto_min_tiles(int alg) {
-    return alg == GRID_ALG_FD_DU ? G::FD_DU_LEAN_AUTO_MIN_TILES : (alg == GRID_ALG_ID_DU ? G::ID_DU_LEAN_AUTO_MIN_TILES : (alg == GRID_ALG_FD ? G::FD_LEAN_AUTO_MIN_TILES : 0));
+    return alg == GRID_ALG_FD_DU ? G::FD_DU_LEAN_AUTO_MIN_TILES : (alg == GRID_ALG_ID_DU ? G::ID_DU_LEAN_AUTO_MIN_TILES : (alg == GRID_ALG_FD ? G::FD_LEAN_AUTO_MIN_TILES
+         : (alg == GRID_ALG_MINV ? G::MINV_LEAN_AUTO_MIN_TILES : 0)));
 }
 // 0: neither, 1: the 4-wave tile-cooperative kernel, 2: its register-lean 8-wave variant (two waves per SIMD, <= 256 registers each)
 static int coop_variant(const grid_handle *h, int alg, int K, const float *d_qdd, const float *d_Minv) {
@@ -258,7 +260,7 @@ static int coop_variant(const grid_handle *h, int alg, int K, const float *d_qdd
     if (h->coop[alg] == 2) return coop_available(alg) ? 1 : 0;
     if (h->split[alg] != 0 || h->pipeline[alg] == 2 || h->wave[alg] == 2) return 0;              // an explicit choice of another variant wins
     const int tiles = (K + G::GRID_WAVE_SIZE - 1) / G::GRID_WAVE_SIZE;
-    const int lean_max = (alg == GRID_ALG_FD) ? G::FD_LEAN_AUTO_MAX_TILES : 0;       // (forward dynamics: beyond two tiles per CU the lane kernel wins)
+    const int lean_max = (alg == GRID_ALG_FD) ? G::FD_LEAN_AUTO_MAX_TILES : (alg == GRID_ALG_MINV) ? G::MINV_LEAN_AUTO_MAX_TILES : 0;       // (forward dynamics: beyond two tiles per CU the lane kernel wins)
     if (lean_available(alg) && lean_auto_min_tiles(alg) > 0 && tiles >= lean_auto_min_tiles(alg) && (lean_max == 0 || tiles <= lean_max)) return 2;
     if (coop_available(alg) && G::FD_DU_COOP_AUTO_MIN_TILES > 0 && tiles >= G::FD_DU_COOP_AUTO_MIN_TILES) return 1;      // (the generated header knows: see its comment)
     return 0;
@@ -284,7 +286,8 @@ static int wave_auto_max_k(int alg) {
     const int k = wave_auto_max_k_header(alg);
     const int cap = (alg == GRID_ALG_FD_DU && G::FD_DU_LEAN_WAVES > 0) ? G::FD_DU_LEAN_WAVE_MAX_K
                   : (alg == GRID_ALG_ID_DU && G::ID_DU_LEAN_WAVES > 0) ? G::ID_DU_LEAN_WAVE_MAX_K
-                  : (alg == GRID_ALG_FD && G::FD_LEAN_WAVES > 0) ? G::FD_LEAN_WAVE_MAX_K : 0;
+                  : (alg == GRID_ALG_FD && G::FD_LEAN_WAVES > 0) ? G::FD_LEAN_WAVE_MAX_K
+                  : (alg == GRID_ALG_MINV && G::MINV_LEAN_WAVES > 0) ? G::MINV_LEAN_WAVE_MAX_K : 0;
     return (cap > 0 && cap < k) ? cap : k;
 }
 static bool wave_available(int alg) { return alg >= 0 && alg <= 4 && G::FD_DU_WAVE_WAVES > 0; }
@@ -346,6 +349,7 @@ static int launch_alg(grid_handle *h, int alg, float *d_out, const float *d_in, 
                           tile_blocks = (int)((cfgs + G::GRID_WAVE_SIZE - 1) / G::GRID_WAVE_SIZE); }
         if (alg == GRID_ALG_ID_DU) G::inverse_dynamics_gradient_lean_launch<T>(d_out, d_in, stride, h->d_robotModel, gravity, K, tile_blocks, s);
         else if (alg == GRID_ALG_FD) G::forward_dynamics_lean_launch<T>(d_out, d_in, stride, h->d_robotModel, gravity, K, tile_blocks, s);
+        else if (alg == GRID_ALG_MINV) G::direct_minv_lean_launch<T>(d_out, d_in, stride, h->d_robotModel, K, tile_blocks, s);
         else if (coop_variant(h, alg, K, d_qdd, d_Minv) == 2) G::forward_dynamics_gradient_lean_launch<T>(d_out, d_in, stride, h->d_robotModel, gravity, K, tile_blocks, s);
         else G::forward_dynamics_gradient_coop_launch<T>(d_out, d_in, stride, h->d_robotModel, gravity, K, tile_blocks, s);
         return grid_check("kernel launch (tile-cooperative)");
@@ -504,6 +508,7 @@ int grid_kernel_attributes_lean(int alg, int *out) {
     hipFuncAttributes a;
     if (alg == GRID_ALG_ID_DU) G::inverse_dynamics_gradient_lean_attributes<T>(&a);
     else if (alg == GRID_ALG_FD) G::forward_dynamics_lean_attributes<T>(&a);
+    else if (alg == GRID_ALG_MINV) G::direct_minv_lean_attributes<T>(&a);
     else G::forward_dynamics_gradient_lean_attributes<T>(&a);
     if (int rc = grid_check("grid_kernel_attributes_lean")) return rc;
     out[0] = a.numRegs; out[1] = (int)a.sharedSizeBytes; out[2] = (int)a.localSizeBytes; out[3] = a.maxThreadsPerBlock;

@@ -322,6 +322,7 @@ class LeanRole:
     Every wave executes the same four barriers."""
 
     out_qdd = False         # (forward-dynamics kernel on the same block, lean_plan_fd: this wave writes qdd to the output after B3)
+    out_minv = False        # (Minv kernel on the same block, lean_plan_minv: this wave writes its forward-pass columns of Minv after B1)
 
     def __init__(self, name="consumer", joints=(), minv_bwd=(), minv_cols=(), c_roots=(), hoist=(), qdd_rows=(), minv_bwd_cols=None):
         self.name, self.joints, self.minv_bwd, self.minv_cols = name, list(joints), list(minv_bwd), sorted(minv_cols)
@@ -547,6 +548,20 @@ def lean_plan_fd(spec, waves=LEAN_WAVES, **options):
         role.hoist = []
         role.out_qdd = (w == 0)
         out.append((role, []))
+    return slots, out
+
+
+def lean_plan_minv(spec, waves=LEAN_WAVES, **options):
+    """The register-lean block as a DIRECT-Minv kernel: input table (sin, cos only: the input rows may hold nothing but q), backward pass
+    of the recursion once per base-rooted tree, forward pass over all eight waves -- and every wave writes the columns it finishes,
+    upper triangle, from registers (the rows of base joints, final since the backward pass, from LDS).  No bias torques, no qdd."""
+    slots, plan = lean_plan(spec, waves, **options)
+    out = []
+    for role, _ in plan:
+        role.hoist, role.c_roots, role.qdd_rows = [], [], []
+        role.out_minv = True
+        out.append((role, []))
+    slots.table_q_only = True
     return slots, out
 
 
@@ -1705,9 +1720,10 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
                     tr.xch_put(itab["c"][j], trig[j][1])
                 else:
                     tr.xch_put(itab["q"][j], q[j])
-                tr.xch_put(itab["qd"][j], qd[j])
-                if "u" in itab:
-                    tr.xch_put(itab["u"][j], u[j])
+                if not getattr(slots, "table_q_only", False):
+                    tr.xch_put(itab["qd"][j], qd[j])
+                    if "u" in itab:
+                        tr.xch_put(itab["u"][j], u[j])
             tr.barrier()
             # ---- phase 1: backward pass of the Minv recursion (once per tree) | bias torques | parked d/dqd recursions, then B1
             def scratch(j, i):          # U_j (6) and 1/D_j of the backward pass: LDS words BELOW the exchange region -- the waves'
@@ -1787,6 +1803,17 @@ def core_gradient_recompute(spec, kind, use_qdd=False, use_qdd_minv=False, table
                     tr.xch_put(slots.qdd[r], total)
             else:
                 tr.barrier()
+            if getattr(role, "out_minv", False) and role.minv_cols:
+                # Minv kernel (lean_plan_minv): this wave's columns, upper triangle, column by column (n values at row offset n*k of the
+                # n x n output; rows below the diagonal and rows of other trees are zero) -- AFTER B2: a flush goes through the wave's
+                # staging region, where U and 1/D are parked until every wave has finished its forward pass
+                for k in role.minv_cols:
+                    col_vals = [tr.xch_get(slots.minv[(r, k)]) if (r <= k and (r, k) in slots.minv) else tr.zero() for r in range(n)]
+                    for at in range(0, n, AlignedPieces.MAX_PIECE):
+                        chunk = col_vals[at:at + AlignedPieces.MAX_PIECE]
+                        for pos, v_ in enumerate(chunk):
+                            tr.out("piece:%d:%d" % (len(chunk), pos), v_)
+                        tr.out("flush:%d:%d" % (len(chunk), n * k + at), 0.0)
             # ---- phase 3: rows of qdd = Minv_sym (u - c) from the published Minv and c, then B3
             if role.qdd_rows and not partials:
                 umc = {}

@@ -123,7 +123,10 @@ int grid_get_split(grid_handle *h, int alg, int num_timesteps);
  * automatic from ID_DU_LEAN_AUTO_MIN_TILES on; a call with d_qdd != NULL keeps the lane-per-configuration kernel.
  * And FORWARD DYNAMICS itself (`forward_dynamics_kernel_coop8`, alg = GRID_ALG_FD: the gradient kernel's prefix -- input table, shared
  * Minv recursion, bias torques, qdd rows -- then one wave writes qdd; replaces algorithms/_forward_dynamics.py:21-112's block per
- * configuration for large robots): grid_lean_available(GRID_ALG_FD), grid_set_coop(h, GRID_ALG_FD, 0|1|3), FD_LEAN_AUTO_MIN_TILES. */
+ * configuration for large robots): grid_lean_available(GRID_ALG_FD), grid_set_coop(h, GRID_ALG_FD, 0|1|3), FD_LEAN_AUTO_MIN_TILES.
+ * And the direct Minv (`direct_minv_kernel_coop8`, alg = GRID_ALG_MINV: input table, backward pass per tree, forward pass over all waves,
+ * columns written from registers; reads q only; replaces algorithms/_direct_minv.py:23-382's block per configuration): the same calls
+ * with GRID_ALG_MINV, MINV_LEAN_AUTO_MIN_TILES / _MAX_TILES. */
 int grid_coop_available(int alg);
 int grid_lean_available(int alg);
 int grid_set_coop(grid_handle *h, int alg, int mode);

@@ -281,6 +281,27 @@ def test_lean_forward_dynamics_block_matches_oracle(robots, tables):
     assert total < 20000, total                # (a quarter of the gradient kernel's tile: 15.7 k instructions for Atlas-30)
 
 
+def test_lean_direct_minv_block_matches_oracle(robots, tables):
+    """cores.lean_plan_minv: the register-lean block as a direct-Minv kernel -- table of sin / cos only (the cores read nothing but q),
+    no bias torques, no qdd; every wave writes the columns of its forward pass, upper triangle, the rest of the n x n output zero."""
+    from oracle import rbd_oracle as O
+    spec = RobotSpec(robots("atlas30"))
+    n, K = spec.n, 3
+    q, qd, u = (a.astype(np.float64) for a in make_inputs(n, K, 69))
+    Minv = O.fd_grad(tables("atlas30"), q, qd, u, return_parts=True)[1]["Minv"]
+    ref = O.flat_colmajor(np.triu(Minv))
+    slots, plan = cores.lean_plan_minv(spec)
+    traces = [cores.core_gradient_recompute(spec, "fd", cols=items, coop=(role, slots)) for (role, items) in plan]
+    for tr in traces:           # nothing but q is read from the input rows (stride_q may be NUM_JOINTS)
+        live = tr.live_nodes()
+        reads = set(tr.nodes[k][1].split("(")[0] for k in range(1, len(tr.nodes)) if live[k] and tr.nodes[k][0] == "in" and not tr.nodes[k][1].startswith("in.xch"))
+        assert reads <= {"in.q"}, reads
+    got, _ = emulate_lean_block(spec, slots, plan, q, qd, u)
+    assert not np.isnan(got[:, :n * n]).any() and np.isnan(got[:, n * n:]).all()
+    assert relerr(got[:, :n * n], ref)[0] < 1e-6
+    assert np.all(got[:, :n * n][:, np.abs(ref).max(axis=0) == 0.0] == 0.0)
+
+
 def test_lean_cores_stay_within_half_a_simd(robots):
     """The point of the exercise: the values a lean core holds at once (creation-order emission, the order the kernel is emitted in)
     stay far below 256 -- the 4-wave cores of the same robot hold 280-390 in their prologue alone -- and the block's LDS fits the CU."""
@@ -522,4 +543,47 @@ def test_lean_forward_dynamics_kernel_on_gpu(tables):
             print("lean FD kernel K=%d: qdd error %.2e (lane-per-configuration kernel %.2e)" % (K, err, relerr(lanes.cpu().numpy(), ref)[0]))
             assert err < min(TOL[robot]["qdd"], NORTH_STAR), (K, err)
             assert relerr(outs[0], lanes.cpu().numpy().astype(np.float64))[0] < 2 * TOL[robot]["qdd"]
+        h.set_coop(alg, 0); h.set_wave(alg, 0)
+
+
+@pytest.mark.gpu
+def test_lean_direct_minv_kernel_on_gpu(tables):
+    """`direct_minv_kernel_coop8` through the C ABI: Minv against the oracle and the lane-per-configuration kernel, ragged batches, few
+    blocks, rows past the batch untouched, an input of q only (stride NUM_JOINTS: the kernel must read nothing else), no scratch."""
+    import torch
+    from gridcodegenerator_amd import host
+    from test_gpu_parity import TOL, oracle_all, pack
+    robot, alg = "atlas30", host.ALG_MINV
+    T = tables(robot)
+    with host.GridHandle(robot, device=0, precision=host.DEFAULT_PRECISION) as h:
+        assert h.lean_available(alg)
+        attrs = h.L.kernel_attributes(alg, coop=2)
+        assert attrs["numRegs"] <= 256 and attrs["scratch_bytes_per_lane"] == 0, attrs
+        n = h.n
+        assert h.get_coop(alg, 4096) == 2 and h.get_coop(alg, 16384) == 2 and h.get_coop(alg, 32768) == 0
+        for K in (1, 70, 333, 1500):
+            q, qd, u = make_inputs(n, K, 390 + K)
+            ref = oracle_all(T, q, qd, u)["Minv"]
+            d_in = torch.from_numpy(pack(q, qd, u)).cuda()
+            h.set_coop(alg, 1); h.set_wave(alg, 1)
+            lanes = torch.zeros((K, n * n), dtype=torch.float32, device="cuda")
+            h.direct_minv_device(lanes.data_ptr(), d_in.data_ptr(), 3 * n, K); h.synchronize()
+            h.set_coop(alg, 3)
+            outs = []
+            for blocks in (0, 1, 2):
+                out = torch.full((K + 2, n * n), 4.25, dtype=torch.float32, device="cuda")
+                h.direct_minv_device(out.data_ptr(), d_in.data_ptr(), 3 * n, K, blocks=blocks); h.synchronize()
+                o = out.cpu().numpy()
+                assert np.all(o[K:] == 4.25)
+                outs.append(o[:K])
+            assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+            err = relerr(outs[0], ref)[0]
+            print("lean Minv kernel K=%d: error %.2e (lane-per-configuration kernel %.2e)" % (K, err, relerr(lanes.cpu().numpy(), ref)[0]))
+            assert err < TOL[robot]["Minv"], (K, err)
+            assert np.all(outs[0][:, np.abs(ref).max(axis=0) == 0.0] == 0.0)
+            # q only, tightly packed, at the very end of its allocation: reading qd or u would run past it
+            d_q = torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32)).cuda()
+            out = torch.zeros((K, n * n), dtype=torch.float32, device="cuda")
+            h.direct_minv_device(out.data_ptr(), d_q.data_ptr(), n, K); h.synchronize()
+            assert np.array_equal(out.cpu().numpy(), outs[0])
         h.set_coop(alg, 0); h.set_wave(alg, 0)
